@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE ONLY — host-compiled build of the device core headers
+// (raytracing_rust_amd/csrc/core/*.h).  It lets the CPU-only test tier step
+// through the very code the HIP kernels run (hit-program traversal, shading,
+// RNG addressing) against the oracle without a GPU.  The product library does
+// not contain, link or load this file; it has no CPU path.
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "../../raytracing_rust_amd/csrc/core/rt_shade.h"
+
+using namespace rt;
+
+extern "C" {
+
+int sim_first_hit(const rtx_scene_desc* S, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
+                  uint32_t* mat_id, uint8_t* front) {
+  for (size_t i = 0; i < n; ++i) {
+    const double* r = rays + 7 * i;
+    Ray ray;
+    ray.o = v3(r[0], r[1], r[2]); ray.d = v3(r[3], r[4], r[5]); ray.tm = r[6];
+    Hit h;
+    bool any = closest_hit<false>(*S, S->world_begin, S->world_end, ray, 0, 0.001, RT_INF, h, nullptr, 0);
+    Surface sf;
+    if (any) resolve_hit(*S, ray, h, false, sf);
+    if (t) t[i] = any ? h.t : RT_INF;
+    if (normal) { normal[3 * i] = any ? sf.n.x : 0; normal[3 * i + 1] = any ? sf.n.y : 0; normal[3 * i + 2] = any ? sf.n.z : 0; }
+    if (prim_id) prim_id[i] = any ? sf.prim_id : 0xFFFFFFFFu;
+    if (mat_id) mat_id[i] = any ? sf.mat : 0xFFFFFFFFu;
+    if (front) front[i] = any ? (sf.front ? 1 : 0) : 0;
+  }
+  return 0;
+}
+
+// counters: paths, segments, pdf_probes
+int sim_render(const rtx_scene_desc* S, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
+               uint64_t* counters, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  const int W = cam->image_width;
+  std::atomic<int> next_row(o->y0);
+  std::vector<uint64_t> segs((size_t)nthreads, 0), probes((size_t)nthreads, 0), paths((size_t)nthreads, 0);
+  auto worker = [&](int tid) {
+    for (;;) {
+      int j = next_row.fetch_add(1);
+      if (j >= o->y1) break;
+      for (int i = o->x0; i < o->x1; ++i) {
+        V3 sum = v3(0, 0, 0);
+        for (int sidx = o->sample_begin; sidx < o->sample_end; ++sidx) {
+          uint32_t sg = 0, pb = 0;
+          sum = sum + trace_path(*S, *cam, o->use_lights != 0 && S->has_lights != 0, i, j, sidx, o->seed, sg, pb);
+          segs[(size_t)tid] += sg; probes[(size_t)tid] += pb; paths[(size_t)tid] += 1;
+        }
+        double* a = accum + ((size_t)j * (size_t)W + (size_t)i) * 3;
+        a[0] += sum.x; a[1] += sum.y; a[2] += sum.z;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+  worker(0);
+  for (auto& t : th) t.join();
+  if (counters) {
+    counters[0] = counters[1] = counters[2] = 0;
+    for (int t = 0; t < nthreads; ++t) { counters[0] += paths[(size_t)t]; counters[1] += segs[(size_t)t]; counters[2] += probes[(size_t)t]; }
+  }
+  return 0;
+}
+
+void sim_resolve_rgb8(const double* accum, int w, int h, int spp, uint8_t* rgb) {
+  double scale = 1.0 / (double)spp;
+  for (size_t i = 0; i < (size_t)w * (size_t)h * 3; ++i) rgb[i] = resolve_channel(accum[i], scale);
+}
+
+// Probes of single device functions for unit tests.
+double sim_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n) {
+  PathRng r = rng_make(seed, pixel, sample);
+  r.stream = stream; r.n = n;
+  return rng_next(r);
+}
+void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32(c[0], c[1], c[2], c[3], k[0], k[1], out); }
+void sim_texture_value(const rtx_scene_desc* S, uint32_t tex, const double* uvp, size_t n, double* out) {
+  for (size_t i = 0; i < n; ++i) {
+    V3 c = texture_value(*S, tex, uvp[5 * i], uvp[5 * i + 1], v3(uvp + 5 * i + 2));
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+  }
+}
+void sim_lights_pdf(const rtx_scene_desc* S, const double* origin, const double* dirs, size_t n, double* out) {
+  for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); }
+}
+void sim_lights_random(const rtx_scene_desc* S, const double* origin, uint64_t seed, size_t n, double* out) {
+  for (size_t i = 0; i < n; ++i) {
+    PathRng r = rng_make(seed, (uint32_t)i, 0);
+    V3 d = lights_random(*S, v3(origin), r);
+    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+  }
+}
+void sim_camera_ray(const rtx_camera_desc* cam, int i, int j, int sample_idx, uint64_t seed, double* out7) {
+  PathRng r = rng_make(seed, (uint32_t)(j * cam->image_width + i), (uint32_t)sample_idx);
+  Ray ray = camera_ray(*cam, i, j, sample_idx, r);
+  out7[0] = ray.o.x; out7[1] = ray.o.y; out7[2] = ray.o.z; out7[3] = ray.d.x; out7[4] = ray.d.y; out7[5] = ray.d.z; out7[6] = ray.tm;
+}
+
+}  // extern "C"
