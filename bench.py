@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s on the reference's `final` scene (800x800, 4900-sample stratification, depth 75).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch: every pixel of the 800x800 frame traced for one row of the 70x70
+stratification (70 consecutive sample indices), i.e. 44.8 M camera paths.  Rank r takes its own disjoint sample rows
+(weak scaling: per-GPU work is fixed), all ranks' accumulators are summed on rank 0 with one reduce (RCCL) inside
+the timed region, and rank 0 copies the sum to the host.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
+SEGMENT_BYTES = 328                          # algorithmic bytes per ray segment of a whole bounce
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(threads, rows=1, samples=8):
+    """The oracle (a C++ restatement of the reference, test infrastructure) on the host cores, bounded sample of the
+    same workload: the full 800x800 frame, `samples` sample indices of the 4900, depth 75."""
+    import raytracing_rust_amd as rt
+    import helpers as H
+    g = H.oracle_graph()
+    w, l, cam = rt.scenes.build("final", g, width=WIDTH, spp=SPP, depth=DEPTH, prefix="orc_", lib=H.oracle_lib())
+    t0 = time.perf_counter()
+    _, cnt = H.oracle_render(g, w, l, cam, sample_begin=0, sample_end=samples, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": cnt["paths"] / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"final scene 800x800, sample indices [0,{samples}) of 4900, depth 75: {cnt['paths']} paths in {dt:.1f} s",
+            "Msegments_per_s": cnt["segments"] / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import raytracing_rust_amd as rt
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = rt.Context(local_rank)
+    g = rt.Graph()
+    world, lights, cam = rt.scenes.build("final", g, width=WIDTH, spp=SPP, depth=DEPTH)
+    scene = rt.Scene.from_graph(ctx, g, world, lights)
+    rows = cam.sqrt_spp                      # 70 sample indices per row, 70 rows
+    npix = cam.image_width * cam.image_height
+    accum = torch.zeros(npix * 3, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k):
+        # row index unique per (rank, step); past the 70 rows of the stratification, wrap with another seed
+        row = rank * (args.steps + args.warmup) + k
+        opts = rt.render_opts(cam, sample_begin=(row % rows) * rows, sample_end=(row % rows + 1) * rows,
+                              seed=rt.scenes.PATH_SEED + row // rows, pipeline=args.pipeline)
+        scene.render_device(cam, opts, accum, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    ctx.reset_stats()
+    accum.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    if dist is not None:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        host = accum.cpu()
+    fence()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    if dist is not None:
+        t = torch.tensor([dt, float(st["segments"]), float(st["paths"])], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, segments, paths = float(tmax[0]), float(t[1]), float(t[2])
+    else:
+        segments, paths = float(st["segments"]), float(st["paths"])
+
+    if rank == 0:
+        assert bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
+        assert paths == npix * rows * args.steps * world_size
+        kernel_ms = st["render_ms"] / max(1, st["launches"])         # HIP events around each launch, rank 0's stream
+        seg_per_launch = st["segments"] / max(1, st["launches"])
+        achieved = seg_per_launch * SEGMENT_BYTES / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Msamples/s (node) final scene 800x800", "value": paths / dt / 1e6, "unit": "Msamples/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "final scene (final_scene.rs) 800x800, depth 75, step = 70 sample indices/pixel of the "
+                                   "4900-sample stratification = 44.8M camera paths per GPU per step",
+                       "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator"},
+            "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_render_fused", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": seg_per_launch * SEGMENT_BYTES},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(threads, samples=args.cpu_samples)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    scene.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

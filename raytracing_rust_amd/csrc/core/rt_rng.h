@@ -24,10 +24,11 @@ struct PathRng {
   uint32_t n;           // counter word 0: draw counter inside the stream
 };
 
-RT_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+template <int ROUNDS>
+RT_HD void philox4x32_r(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 RT_UNROLL
-  for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
+  for (int r = 0; r < ROUNDS; ++r) {
     uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -35,6 +36,9 @@ RT_UNROLL
     k0 += W0; k1 += W1;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+RT_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+  philox4x32_r<RT_PHILOX_ROUNDS>(c0, c1, c2, c3, k0, k1, out);
 }
 
 RT_HD double u53(uint32_t hi, uint32_t lo) {  // uniform in [0,1) with 53 random bits, like rand's f64 sampling

@@ -78,6 +78,7 @@ double sim_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t s
   return rng_next(r);
 }
 void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32(c[0], c[1], c[2], c[3], k[0], k[1], out); }
+void sim_philox10(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32_r<10>(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 void sim_texture_value(const rtx_scene_desc* S, uint32_t tex, const double* uvp, size_t n, double* out) {
   for (size_t i = 0; i < n; ++i) {
     V3 c = texture_value(*S, tex, uvp[5 * i], uvp[5 * i + 1], v3(uvp + 5 * i + 2));

@@ -1,0 +1,106 @@
+"""Deterministic scene recipes for the parity tests.  Each takes a Graph (oracle- or product-backed), builds the same
+graph through the reference-shaped constructors and returns (world, lights, rays[n,7])."""
+import numpy as np
+
+
+def _rays_towards(rng, n, center, radius, dist):
+    """Random rays from a shell of radius `dist` aimed near `center` (unnormalised directions, random time)."""
+    o = rng.normal(size=(n, 3))
+    o = center + dist * o / np.linalg.norm(o, axis=1, keepdims=True)
+    target = center + rng.uniform(-radius, radius, size=(n, 3))
+    d = (target - o) * rng.uniform(0.2, 3.0, size=(n, 1))
+    return np.concatenate([o, d, rng.uniform(0, 1, size=(n, 1))], axis=1)
+
+
+def _materials(g):
+    return [g.lambertian_color(0.5, 0.5, 0.5), g.metal(0.8, 0.8, 0.9, 0.3), g.dielectric(1.5),
+            g.diffuse_light_color(4, 4, 4), g.none()]
+
+
+def _random_leaf(g, rng, mats, span=100.0):
+    m = mats[int(rng.integers(len(mats)))]
+    kind = int(rng.integers(4))
+    c = rng.uniform(-span, span, size=3)
+    if kind == 0:
+        return g.sphere(c, float(rng.uniform(2, 15)), m)
+    if kind == 1:
+        return g.sphere_moving(c, c + rng.uniform(-10, 10, size=3), float(rng.uniform(2, 15)), m)
+    if kind == 2:
+        return g.quad(c, rng.uniform(-30, 30, size=3), rng.uniform(-30, 30, size=3), m)
+    return g.box(c, c + rng.uniform(-25, 25, size=3), m)
+
+
+def flat_random_prims(g):
+    rng = np.random.default_rng(101)
+    mats = _materials(g)
+    world = g.list([_random_leaf(g, rng, mats) for _ in range(60)])
+    return world, None, _rays_towards(rng, 6000, np.zeros(3), 110.0, 400.0)
+
+
+def bvh_mixed_leaves(g):
+    """BVH over 37 mixed leaves: exercises spans 1, 2 and 3 of the median split and list leaves (boxes)."""
+    rng = np.random.default_rng(102)
+    mats = _materials(g)
+    leaves = g.list([_random_leaf(g, rng, mats) for _ in range(37)])
+    world = g.list([g.bvh(leaves), g.sphere((0, 0, 0), 20.0, mats[2])])
+    return world, None, _rays_towards(rng, 6000, np.zeros(3), 110.0, 350.0)
+
+
+def nested_transforms(g):
+    """Translate(RotateY(Translate(..))), a BVH whose leaves are transformed BVHs, and a transformed single-leaf BVH."""
+    rng = np.random.default_rng(103)
+    mats = _materials(g)
+    inner = g.bvh(g.list([_random_leaf(g, rng, mats, 40.0) for _ in range(9)]))
+    a = g.translate(g.rotate_y(g.translate(inner, (5, -3, 7)), 33.0), (60, 10, -20))
+    b = g.rotate_y(g.translate(g.rotate_y(g.box((0, 0, 0), (30, 50, 20), mats[0]), -71.0), (-80, 0, 30)), 12.5)
+    c = g.translate(g.bvh(g.list([g.sphere((0, 0, 0), 12.0, mats[1])])), (0, 70, 0))
+    leaves = g.list([a, b, c] + [_random_leaf(g, rng, mats) for _ in range(6)])
+    world = g.list([g.bvh(leaves), g.quad((-150, -60, -150), (300, 0, 0), (0, 0, 300), mats[0])])
+    return world, None, _rays_towards(rng, 6000, np.zeros(3), 120.0, 420.0)
+
+
+def ties_edges_and_axis_parallel(g):
+    """Rays through box edges and corners, along axes (|d_k| < 1e-8 skips that slab axis), starting on surfaces,
+    plus degenerate rays (zero and NaN directions)."""
+    rng = np.random.default_rng(104)
+    mats = _materials(g)
+    boxes = [g.box((x, 0, z), (x + 10, 10 + ((x * 7 + z * 3) % 5), z + 10), mats[0]) for x in range(-30, 30, 10) for z in range(-30, 30, 10)]
+    world = g.list([g.bvh(g.list(boxes)), g.sphere((0, 25, 0), 10.0, mats[2]),
+                    g.quad((-30, 0, -30), (60, 0, 0), (0, 0, 60), mats[0])])
+    rays = []
+    for x in range(-30, 31, 10):          # straight down onto shared box edges / corners (two exact-zero components)
+        for z in range(-30, 31, 5):
+            rays.append([x, 50, z, 0, -1, 0, 0.0])
+            rays.append([x, 50, z, 0, -2.5, 0, 0.5])
+    for y in (0.0, 5.0, 10.0, 12.0):       # grazing along x and z at face heights
+        for z in range(-30, 31, 10):
+            rays.append([-100, y, z, 1, 0, 0, 0.0])
+            rays.append([z, y, -100, 0, 0, 3, 0.0])
+    for _ in range(500):                    # one tiny component (below and above the 1e-8 threshold)
+        o = rng.uniform(-40, 40, size=3); o[1] = 60
+        d = np.array([rng.uniform(-1, 1), -1.0, rng.choice([1e-9, -1e-9, 1e-7, 0.0, -0.0])])
+        rays.append([*o, *d, 0.0])
+    for _ in range(500):                    # origins exactly on the ground quad / sphere surface
+        p = np.array([rng.uniform(-30, 30), 0.0, rng.uniform(-30, 30)])
+        rays.append([*p, *rng.normal(size=3), 0.0])
+    rays.append([0, 50, 0, 0, 0, 0, 0.0])
+    rays.append([0, 50, 0, np.nan, -1, 0, 0.0])
+    rays.append([np.nan, 50, 0, 0, -1, 0, 0.0])
+    rays.append([0, 50, 0, np.inf, -1, 0, 0.0])
+    return world, None, np.array(rays, dtype=np.float64)
+
+
+def empty_lists_and_media(g):
+    """Empty lists at several places, a medium (skipped by the deterministic AOV) and its boundary shared with the
+    world, as in the reference's final scene."""
+    rng = np.random.default_rng(105)
+    mats = _materials(g)
+    boundary = g.sphere((0, 0, 0), 30.0, mats[2])
+    fog = g.medium(g.sphere((0, 0, 0), 500.0, mats[2]), 0.001, g.solid(1, 1, 1))
+    smoke_box = g.medium(g.translate(g.rotate_y(g.box((0, 0, 0), (20, 20, 20), mats[0]), 20.0), (40, 0, 0)), 0.05, g.solid(0, 0, 0))
+    inner = g.list([g.list(), boundary, g.medium(boundary, 0.2, g.solid(0.2, 0.4, 0.9)), g.list()])
+    world = g.list([g.list(), inner, fog, smoke_box, g.bvh(g.list([g.list([g.sphere((60, 0, 60), 10.0, mats[0])])]))])
+    return world, None, _rays_towards(rng, 3000, np.zeros(3), 70.0, 200.0)
+
+
+ALL = [flat_random_prims, bvh_mixed_leaves, nested_transforms, ties_edges_and_axis_parallel, empty_lists_and_media]

@@ -1,0 +1,131 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import raytracing_rust_amd as rt
+from raytracing_rust_amd import _capi, scenes
+import helpers as H
+import recipes
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name, **kw):
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam_o = scenes.build(name, go, prefix="orc_", lib=H.oracle_lib(), **kw)
+    wp, lp, cam = scenes.build(name, gp, **kw)
+    assert bytes(cam_o) == bytes(cam)
+    return go, wo, lo, gp, wp, lp, cam
+
+
+@pytest.mark.parametrize("name,width", [("cornell", 600), ("smoke", 300), ("final", 800), ("quick", 400)])
+def test_first_hit_aov_bit_exact_named_scenes(gpu_ctx, name, width):
+    """t, normal, primitive id, material id and front flag on every pixel-centre ray, at BASELINE sizes."""
+    go, wo, lo, gp, wp, lp, cam = _pair(name, width=width)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    rays = rt.pixel_center_rays(cam, time=0.37)
+    H.assert_aov_equal(H.oracle_first_hit(go, wo, rays), scene.first_hit(rays), name)
+    scene.close()
+
+
+@pytest.mark.parametrize("recipe", recipes.ALL, ids=lambda r: r.__name__)
+def test_first_hit_aov_bit_exact_recipes(gpu_ctx, recipe):
+    """Random and edge-case graphs: nested transforms, BVHs of mixed leaves, ties, axis-parallel rays, empty lists."""
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, _, rays = recipe(go)
+    wp, _, _ = recipe(gp)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, None)
+    H.assert_aov_equal(H.oracle_first_hit(go, wo, rays), scene.first_hit(rays), recipe.__name__)
+    scene.close()
+
+
+def test_gpu_matches_host_build_of_same_code(gpu_ctx):
+    """Same counter-based RNG addressing on both sides: the GPU render and the host build of the device core trace
+    the same paths; only libm-vs-OCML transcendentals differ, so sums agree to a tight tolerance."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("cornell", gp, width=48, spp=16, depth=12)
+    desc = rt.flatten(gp, wp, lp)
+    scene = rt.Scene(gpu_ctx, desc)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=11))
+    st = gpu_ctx.stats()
+    b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, seed=11))
+    assert st["paths"] == cb["paths"] == 48 * 48 * 16
+    assert abs(st["segments"] - cb["segments"]) <= 0.002 * cb["segments"]
+    close = np.isclose(a, b, rtol=1e-6, atol=1e-9)
+    assert close.mean() > 0.995, f"only {close.mean():.4f} of the channels agree"
+    scene.close()
+
+
+@pytest.mark.parametrize("name,spp,depth", [("cornell", 400, 50), ("smoke", 400, 50), ("quick", 144, 20)])
+def test_render_matches_oracle_statistically(gpu_ctx, name, spp, depth):
+    """Converged-image check at equal spp with independent seeds, calibrated by the Monte Carlo noise itself: the
+    8x8-block means of the GPU render must be as close to the oracle's as two GPU renders with different seeds are
+    to each other (factor 1.5 + 0.5 % slack), and the global mean radiance must agree within 1.5 %.
+    Tolerance: relative L1 distance of block means; no bit-exactness is claimed for shaded radiance."""
+    W = 64
+    go, wo, lo, gp, wp, lp, cam = _pair(name, width=W, spp=spp, depth=depth)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    n = cam.sqrt_spp ** 2
+    a1 = scene.render(cam, rt.render_opts(cam, seed=101)) / n
+    a2 = scene.render(cam, rt.render_opts(cam, seed=202)) / n
+    b, _ = H.oracle_render(go, wo, lo, cam)
+    b /= n
+    assert not np.isnan(a1).any()
+    blk = lambda x: x.reshape(W // 8, 8, W // 8, 8, 3).mean(axis=(1, 3))
+    dist = lambda x, y: np.abs(blk(x) - blk(y)).mean() / blk(y).mean()
+    noise = dist(a1, a2)
+    assert dist(a1, b) < 1.5 * noise + 0.005, f"{name}: GPU-vs-oracle {dist(a1, b):.4f}, GPU-vs-GPU noise {noise:.4f}"
+    assert dist(a2, b) < 1.5 * noise + 0.005, f"{name}: GPU-vs-oracle {dist(a2, b):.4f}, GPU-vs-GPU noise {noise:.4f}"
+    rel_mean = abs(0.5 * (a1 + a2).mean() - b.mean()) / b.mean()
+    assert rel_mean < 0.015, f"{name}: mean radiance differs by {rel_mean:.4f}"
+    scene.close()
+
+
+def test_sample_ranges_and_rectangles_add_up(gpu_ctx):
+    """Sharding property: disjoint sample ranges and pixel rectangles sum to the full render (RNG streams are keyed
+    by (pixel, sample), so the shards trace exactly the same paths)."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("cornell", gp, width=40, spp=36, depth=10)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    full = scene.render(cam, rt.render_opts(cam, seed=5))
+    parts = np.zeros_like(full)
+    for (b, e) in [(0, 7), (7, 20), (20, 36)]:
+        scene.render(cam, rt.render_opts(cam, sample_begin=b, sample_end=e, seed=5), parts)
+    np.testing.assert_allclose(parts, full, rtol=1e-12, atol=1e-12)
+    tiles = np.zeros_like(full)
+    for rect in [(0, 0, 17, 40), (17, 0, 40, 9), (17, 9, 40, 40)]:
+        scene.render(cam, rt.render_opts(cam, rect=rect, seed=5), tiles)
+    np.testing.assert_allclose(tiles, full, rtol=1e-12, atol=1e-12)
+    empty = scene.render(cam, rt.render_opts(cam, sample_begin=3, sample_end=3, seed=5))
+    assert not empty.any()
+    scene.close()
+
+
+def test_resolve_bit_exact(gpu_ctx):
+    """color_to_rgb_with_samples: NaN scrub, the requested-spp scale, gamma 2, clamp, truncation."""
+    rng = np.random.default_rng(3)
+    acc = rng.uniform(-1.0, 1200.0, size=(37, 53, 3))
+    acc[0, 0] = (np.nan, 0.0, -0.0)
+    acc[1, 1] = (np.inf, 1e-300, 999.9999)
+    ref = np.empty(acc.shape, dtype=np.uint8)
+    H.oracle_lib().orc_resolve_rgb8(H.dptr(acc), 53, 37, 1000, ref.ctypes.data_as(H.PU8))
+    out = gpu_ctx.resolve_rgb8(acc, 1000)
+    assert (out == ref).all()
+
+
+def test_errors_are_reported_not_thrown(gpu_ctx):
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("cornell", gp, width=16, spp=4, depth=4)
+    desc = rt.flatten(gp, wp, lp)
+    desc.world_end = desc.n_nodes + 5
+    with pytest.raises(rt.RtxError) as e:
+        rt.Scene(gpu_ctx, desc)
+    assert e.value.status == _capi.RTX_ERR_INVALID and "world program" in str(e.value)
+    desc = rt.flatten(gp, wp, lp)
+    scene = rt.Scene(gpu_ctx, desc)
+    with pytest.raises(rt.RtxError):
+        scene.render(cam, rt.render_opts(cam, sample_end=cam.sqrt_spp ** 2 + 1))
+    with pytest.raises(rt.RtxError):
+        scene.render(cam, rt.render_opts(cam, rect=(0, 0, 17, 16)))
+    scene.close()

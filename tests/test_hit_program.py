@@ -1,0 +1,79 @@
+"""CPU tier: the flattened hit program (host layer + device core compiled for the host) against the oracle's
+recursive trait-object traversal.  Bit-exact first-hit AOVs; BVH shape; bounding boxes."""
+import numpy as np
+import pytest
+
+import raytracing_rust_amd as rt
+from raytracing_rust_amd import _capi, scenes
+import helpers as H
+import recipes
+
+
+@pytest.mark.parametrize("name,width", [("cornell", 150), ("smoke", 150), ("final", 200)])
+def test_named_scenes_bit_exact(name, width):
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam_o = scenes.build(name, go, width=width, prefix="orc_", lib=H.oracle_lib())
+    wp, lp, cam = scenes.build(name, gp, width=width)
+    assert bytes(cam_o) == bytes(cam), "Camera::initialize differs between oracle and host layer"
+    for time in (0.0, 0.73):
+        rays = rt.pixel_center_rays(cam, time=time)
+        H.assert_aov_equal(H.oracle_first_hit(go, wo, rays), H.hostsim_first_hit(rt.flatten(gp, wp, lp), rays), name)
+
+
+@pytest.mark.parametrize("recipe", recipes.ALL, ids=lambda r: r.__name__)
+def test_recipes_bit_exact(recipe):
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, _, rays = recipe(go)
+    wp, _, _ = recipe(gp)
+    a = H.oracle_first_hit(go, wo, rays)
+    b = H.hostsim_first_hit(rt.flatten(gp, wp, None), rays)
+    H.assert_aov_equal(a, b, recipe.__name__)
+    assert np.isfinite(a["t"]).sum() > 50, "recipe rays should hit something"
+
+
+def test_final_scene_bvh_shape():
+    """400 leaves -> 511 nodes, 1000 leaves -> 1023 nodes (f(1)=f(2)=1, f(n)=1+f(n/2)+f(n-n/2)), bvh.rs:26-71."""
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=32)
+    d = rt.flatten(g, w, l)
+    assert d.n_boxes == 511 + 1023
+    assert d.n_spheres == 1007 and d.n_quads == 2402
+    assert d.n_media == 2 and d.n_lights == 1 and d.has_lights == 1
+    kinds = np.array([d.nodes[i].kind_idx >> 28 for i in range(d.n_nodes)])
+    assert (kinds[: d.world_end] == _capi.NODE_MEDIUM).sum() == 2
+    assert (kinds == _capi.NODE_ENTER).sum() == 2 and (kinds == _capi.NODE_EXIT).sum() == 2   # rotate inside translate
+    for i in np.nonzero(kinds == _capi.NODE_BOX)[0]:
+        assert i < d.nodes[i].skip <= d.n_nodes
+
+
+def test_bounding_boxes_match_oracle():
+    """Hittable::bounding_box of every implementor, including padding of flat quads and the rotated-corner box."""
+    def recipe(g):
+        m = g.lambertian_color(0.5, 0.5, 0.5)
+        q = g.quad((1, 2, 3), (4, 0, 0), (0, 0, 5), m)                       # flat in y: padded by 1e-4
+        s = g.sphere_moving((0, 0, 0), (3, 1, 0), 2.0, m)
+        b = g.box((0, 0, 0), (1, 2, 3), m)
+        r = g.rotate_y(b, 30.0)
+        t = g.translate(r, (10, 20, 30))
+        lst = g.list([q, s, t])
+        return [q, s, b, r, t, lst, g.bvh(lst), g.medium(s, 0.1, g.solid(1, 1, 1)), g.list(), g.translate(g.list(), (1, 1, 1))]
+    go, gp = H.oracle_graph(), rt.Graph()
+    for ho, hp in zip(recipe(go), recipe(gp)):
+        bo, bp = go.bounding_box(ho), gp.bounding_box(hp)
+        assert (bo is None) == (bp is None)
+        if bo is not None:
+            assert (bo.view(np.uint64) == bp.view(np.uint64)).all()
+
+
+def test_unsupported_graphs_are_rejected():
+    g = rt.Graph()
+    m = g.lambertian_color(0.5, 0.5, 0.5)
+    inner = g.medium(g.sphere((0, 0, 0), 1.0, m), 0.5, g.solid(1, 1, 1))
+    outer = g.medium(g.list([g.sphere((0, 0, 0), 5.0, m), inner]), 0.5, g.solid(1, 1, 1))
+    with pytest.raises(rt.RtxError) as e:
+        rt.flatten(g, g.list([outer]), None)
+    assert e.value.status == _capi.RTX_ERR_UNSUPPORTED
+    with pytest.raises(rt.GraphError):
+        g.bvh(g.list())                     # the reference would index an empty slice
+    with pytest.raises(rt.GraphError):
+        g.sphere((0, 0, 0), 1.0, 9999)      # bad material handle
