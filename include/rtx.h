@@ -188,9 +188,11 @@ typedef struct rtx_stats { /* totals since context creation */
   uint64_t paths;        /* camera paths started */
   uint64_t segments;     /* world closest-hit queries made by the integrator (camera.rs:179) */
   uint64_t pdf_probes;   /* light-leaf pdf_value evaluations (sphere.rs:125, quad.rs:102) */
-  double render_ms;      /* device time of render launches (HIP events) */
-  uint64_t launches;     /* number of render kernel launches */
-  double last_kernel_ms; /* device time of the most recent dominant-kernel launch */
+  double render_ms;      /* stream time of render calls (HIP events around each call) */
+  uint64_t launches;     /* number of render calls */
+  double last_kernel_ms; /* device time of the most recent render call */
+  double traverse_ms;    /* device time of traversal-kernel launches (wavefront pipeline, HIP events) */
+  uint64_t traverse_launches;
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;

@@ -1,0 +1,160 @@
+// Compilation of the boundary's hit program (rtx_scene_desc.nodes) into the layout the kernels walk.
+//
+// The ABI keeps nodes and boxes in separate tables.  For the device the program becomes one array of 8-byte units
+// so that a box test needs a single address: a BOX record is 8 units (header, pad, lo[3], hi[3]; 64 B, 16-byte
+// aligned so that the six doubles can be read as three 16-byte loads from LDS), every other record is one unit.
+// Unit = kind_idx (low 32 bits, as RTX_NODE_MAKE) | skip << 32 (BOX: unit index to continue at on a miss).
+// NOP units keep BOX records on even unit positions; an END unit closes the world program and every medium boundary
+// program, so the walker needs no end index.  Static spheres and quads whose normal is an exact coordinate axis get
+// compact records (DSphere, DAAQuad) and their own unit kinds.  Visiting order and links are unchanged.
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rt_traverse.h"
+
+namespace rt {
+
+struct CompiledProgram {
+  std::vector<uint64_t> units;
+  std::vector<rtx_medium> media;   // copy of the scene's media with b_begin as a unit index (b_end is unused)
+  std::vector<DSphere> dspheres;   // parallel to d.spheres
+  std::vector<DAAQuad> daaquads;   // parallel to d.quads
+  std::vector<uint8_t> sphere_static, quad_aa;
+  uint32_t world_begin = 0;
+
+  // `d` must already be validated (index ranges, forward skip links that stay inside their program).
+  void compile(const rtx_scene_desc& d) {
+    units.clear();
+    build_compact(d);
+    media.assign(d.media, d.media + d.n_media);
+    world_begin = emit_range(d, d.world_begin, d.world_end, true);
+    for (uint32_t m = 0; m < d.n_media; ++m) {
+      media[m].b_begin = emit_range(d, d.media[m].b_begin, d.media[m].b_end, false);
+      media[m].b_end = 0;
+    }
+    if (units.size() & 1u) units.push_back(nop());   // even unit count: the program is copied in 16-byte pieces
+    units.insert(units.end(), PROG_BOX_UNITS, nop()); // tail pad: reads of a whole record never leave the array
+  }
+
+  // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
+  Scene host_view(const rtx_scene_desc& d) const {
+    Scene S;
+    static_cast<rtx_scene_desc&>(S) = d;
+    S.nodes = nullptr; S.n_nodes = 0;
+    S.world_begin = world_begin; S.world_end = 0;
+    S.media = media.data();
+    S.prog = units.data(); S.n_units = (uint32_t)units.size(); S._pad1 = 0;
+    S.dspheres = dspheres.data(); S.daaquads = daaquads.data();
+    return S;
+  }
+
+ private:
+  static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }
+
+  void build_compact(const rtx_scene_desc& d) {
+    dspheres.assign(d.n_spheres, DSphere{0, 0, 0, 0});
+    sphere_static.assign(d.n_spheres, 0);
+    for (uint32_t i = 0; i < d.n_spheres; ++i) {
+      const rtx_sphere& s = d.spheres[i];
+      if (s.dc[0] == 0.0 && s.dc[1] == 0.0 && s.dc[2] == 0.0) {
+        sphere_static[i] = 1;
+        dspheres[i] = DSphere{s.c0[0], s.c0[1], s.c0[2], s.radius};
+      }
+    }
+    DAAQuad zero;
+    memset(&zero, 0, sizeof(zero));
+    daaquads.assign(d.n_quads, zero);
+    quad_aa.assign(d.n_quads, 0);
+    for (uint32_t i = 0; i < d.n_quads; ++i) {
+      const rtx_quad& q = d.quads[i];
+      int k = -1, zeros = 0;
+      for (int c = 0; c < 3; ++c) {
+        if (q.normal[c] == 0.0 && q.w[c] == 0.0) ++zeros;
+        else k = c;
+      }
+      if (zeros != 2 || fabs(q.normal[k]) != 1.0 || !std::isfinite(q.w[k]) || !std::isfinite(q.d)) continue;
+      const int a = (k + 1) % 3, b = (k + 2) % 3;
+      const double vals[8] = {q.q[a], q.q[b], q.u[a], q.u[b], q.v[a], q.v[b], q.q[k], q.u[k] + q.v[k]};
+      bool finite = true;
+      for (double v : vals) finite = finite && std::isfinite(v);
+      if (!finite) continue;
+      quad_aa[i] = 1;
+      DAAQuad& o = daaquads[i];
+      o.d = q.d; o.nk = q.normal[k];
+      o.qa = q.q[a]; o.qb = q.q[b]; o.ua = q.u[a]; o.ub = q.u[b]; o.va = q.v[a]; o.vb = q.v[b]; o.wk = q.w[k];
+      o.axis = (uint32_t)k; o._pad = 0;
+    }
+  }
+
+  // Appends nodes[b,e) + END; returns the unit index of the first record.  Consecutive static spheres / axis-aligned
+  // quads whose table indices are consecutive too (the six faces of a box) become one run unit (count in the high
+  // half); a run never spans a node some box skips to.  With `sync`, a SYNC unit follows every top-level box subtree
+  // of the range (skip links that end such a subtree land on the SYNC).
+  uint32_t emit_range(const rtx_scene_desc& d, uint32_t b, uint32_t e, bool sync) {
+    const uint32_t n = e - b;
+    std::vector<uint8_t> target((size_t)n + 1, 0), sync_before((size_t)n + 1, 0);
+    uint32_t enclosing_end = b;  // nodes before this index lie inside some box subtree
+    for (uint32_t i = b; i < e; ++i) {
+      if (RTX_NODE_KIND(d.nodes[i].kind_idx) != RTX_NODE_BOX) continue;
+      const uint32_t skip = std::min(std::max(d.nodes[i].skip, b), e);  // validated to lie in (i, e]
+      target[skip - b] = 1;
+      if (sync && i >= enclosing_end) sync_before[skip - b] = 1;
+      enclosing_end = std::max(enclosing_end, skip);
+    }
+    struct Item { uint32_t kind, idx, count, node; };
+    std::vector<Item> items;
+    for (uint32_t i = b; i < e; ++i) {
+      uint32_t kind = RTX_NODE_KIND(d.nodes[i].kind_idx);
+      const uint32_t idx = RTX_NODE_IDX(d.nodes[i].kind_idx);
+      if (kind == RTX_NODE_SPHERE && sphere_static[idx]) kind = PROG_NODE_SPHERE_S;
+      else if (kind == RTX_NODE_QUAD && quad_aa[idx]) kind = PROG_NODE_QUAD_AA;
+      const bool run_kind = kind == PROG_NODE_SPHERE_S || kind == PROG_NODE_QUAD_AA;
+      if (run_kind && !items.empty() && !target[i - b] && items.back().kind == kind &&
+          items.back().idx + items.back().count == idx && items.back().node + items.back().count == i &&
+          items.back().count < 64)
+        items.back().count += 1;
+      else
+        items.push_back(Item{kind, idx, 1u, i});
+    }
+    // unit positions; link[k] = where a skip to node b+k lands
+    std::vector<uint32_t> link((size_t)n + 1, 0), item_pos(items.size());
+    uint32_t at = (uint32_t)units.size();
+    for (size_t k = 0; k < items.size(); ++k) {
+      const uint32_t rel = items[k].node - b;
+      const bool box = items[k].kind == RTX_NODE_BOX;
+      if (sync_before[rel]) { link[rel] = at; at += 1; }
+      if (box && (at & 1u)) ++at;  // NOP filler keeps BOX records 16-byte aligned
+      item_pos[k] = at;
+      if (!sync_before[rel]) link[rel] = at;
+      at += box ? PROG_BOX_UNITS : 1u;
+    }
+    if (sync_before[n]) { link[n] = at; at += 1; } else { link[n] = at; }
+    const uint32_t end_at = at;
+    units.resize((size_t)end_at + 1, nop());
+    for (size_t k = 0; k < items.size(); ++k) {
+      const Item& it = items[k];
+      const uint32_t p = item_pos[k], rel = it.node - b;
+      if (sync_before[rel]) units[link[rel]] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_SYNC, 0);
+      if (it.kind == RTX_NODE_BOX) {
+        const rtx_node nd = d.nodes[it.node];
+        const uint32_t skip = std::min(std::max(nd.skip, b), e);
+        units[p] = (uint64_t)nd.kind_idx | ((uint64_t)link[skip - b] << 32);
+        units[p + 1] = 0;
+        memcpy(&units[p + 2], &d.boxes[it.idx], sizeof(rtx_aabb));
+      } else if (it.kind == PROG_NODE_SPHERE_S || it.kind == PROG_NODE_QUAD_AA) {
+        units[p] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
+      } else {
+        units[p] = (uint64_t)d.nodes[it.node].kind_idx;
+      }
+    }
+    if (sync_before[n]) units[link[n]] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_SYNC, 0);
+    units[end_at] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+    return n ? link[0] : end_at;
+  }
+};
+
+}  // namespace rt

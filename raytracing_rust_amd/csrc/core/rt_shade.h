@@ -144,8 +144,8 @@ RT_HD V3 sphere_random(const rtx_sphere& s, const V3& origin, PathRng& rng) {
 }
 // Quad::pdf_value, quad.rs:102-116
 RT_HD double quad_pdf_value(const rtx_quad& q, const V3& origin, const V3& dir) {
-  double t, a, b;
-  if (!quad_hit_t(q, origin, dir, 0.001, RT_INF, t, a, b)) return 0.0;
+  double t;
+  if (!quad_hit_t(q, origin, dir, 0.001, RT_INF, t)) return 0.0;
   double dist2 = t * t * norm2(dir);
   // rec.normal is +-normal; only its absolute cosine is used
   double cosine = fabs(dot(dir, v3(q.normal)) / norm(dir));
@@ -221,10 +221,10 @@ RT_HD double schlick(double cosine, double ratio) {
 }
 
 // Everything ray_color does after world.hit returned (camera.rs:180-246).  Returns true when the path goes on
-// with `next`; false when it ended (ps.L is final).  `hit_any` false = miss (camera.rs:179-181).
-RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, const Ray& wray, bool hit_any,
-                        const Hit& hit, PathState& ps, Ray& next, uint32_t& probes) {
-  if (!hit_any) { ps.L = ps.L + cmul(ps.T, background); return false; }
+// with `next`; false when it ended (ps.L is final).  A hit of kind NONE is a miss (camera.rs:179-181).
+RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, const Ray& wray,
+                        const Hit& hit, const double* stale_uv, PathState& ps, Ray& next, uint32_t& probes) {
+  if (!hit_any(hit)) { ps.L = ps.L + cmul(ps.T, background); return false; }
   rng_stream(ps.rng, ps.bounce, RNG_DOMAIN_SHADE);
   const uint32_t hkind = RTX_NODE_KIND(hit.kind_idx);
   uint32_t mat_idx;
@@ -233,7 +233,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   else mat_idx = S.media[RTX_NODE_IDX(hit.kind_idx)].mat;
   const rtx_material m = S.materials[mat_idx];
   Surface sf;
-  resolve_hit(S, wray, hit, m.needs_uv != 0, sf);
+  resolve_hit(S, wray, hit, m.needs_uv != 0, stale_uv, sf);
 
   // emission (camera.rs:184; diffuse_light.rs:37-39: both faces emit)
   if (m.kind == RTX_MAT_DIFFUSE_LIGHT) {
@@ -351,10 +351,13 @@ RT_HD V3 trace_path(const Scene& S, const rtx_camera_desc& cam, bool use_lights,
   bool alive = ps.depth > 0;
   while (alive) {
     Hit hit;
+    double stale_uv[2] = {0.0, 0.0};
     ++segments;
-    bool any = closest_hit<true>(S, S.world_begin, S.world_end, ray, 0, 0.001, RT_INF, hit, &ps.rng, ps.bounce);
+    RayRegs rs;
+    rs.r = ray;
+    closest_hit<true>(S, S.prog, S.world_begin, true, rs, ray.tm, 0.001, RT_INF, hit, true, ps.rng, ps.bounce, stale_uv);
     Ray next;
-    alive = shade_bounce(S, bg, use_lights, ray, any, hit, ps, next, probes);
+    alive = shade_bounce(S, bg, use_lights, ray, hit, stale_uv, ps, next, probes);
     ray = next;
   }
   return ps.L;

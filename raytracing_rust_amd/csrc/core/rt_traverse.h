@@ -1,4 +1,4 @@
-// Closest-hit query over a flattened hit program (see rtx.h: rtx_node).
+// Closest-hit query over a compiled hit program (see rtx.h: rtx_node, and rt_program.h).
 //
 // The reference walks a graph of trait objects recursively
 // (hittable_list.rs:53-67, bvh.rs:87-105, translate.rs:35-47,
@@ -16,18 +16,51 @@
 
 namespace rt {
 
-typedef rtx_scene_desc Scene;  // on the device the pointers are device pointers
+// Compact primitive records the traversal reads instead of the ABI's full records (fewer, narrower loads).
+struct DSphere {   // static sphere: centre and radius (sphere.rs:84 with a zero displacement)
+  double cx, cy, cz, r;
+};
+struct DAAQuad {   // quad whose normal is exactly +-e_k (box faces, Cornell walls): only the terms that are not
+  double d, nk;    // multiplied by an exact zero survive in quad.rs:67-82; k = axis, (a, b) = (k+1, k+2) mod 3
+  double qa, qb, ua, ub, va, vb, wk;
+  uint32_t axis, _pad;
+};
+
+// The scene as the kernels see it: the tables of rtx_scene_desc (device pointers on the GPU) plus the compiled hit
+// program (rt_program.h).  world_begin and media[].b_begin are UNIT indices into `prog` here.
+struct Scene : rtx_scene_desc {
+  const uint64_t* prog;
+  const DSphere* dspheres;   // parallel to spheres[]; valid where the program uses PROG_NODE_SPHERE_S
+  const DAAQuad* daaquads;   // parallel to quads[]; valid where the program uses PROG_NODE_QUAD_AA
+  uint32_t n_units, _pad1;
+};
+#define PROG_BOX_UNITS 8u        // a BOX record: header unit, pad unit, six doubles
+#define PROG_NODE_NOP 6u         // alignment filler
+#define PROG_NODE_END 7u         // end of a program (the world's, or a medium boundary's)
+#define PROG_NODE_SPHERE_S 8u    // run of static spheres, compact records (hits are reported as RTX_NODE_SPHERE)
+#define PROG_NODE_QUAD_AA 9u     // run of axis-aligned quads, compact records (hits are reported as RTX_NODE_QUAD)
+#define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
+
+// Wave-level votes.  On the GPU they steer the 64 lanes of a wave through the traversal loop together; in the host
+// build a "wave" is one ray and they reduce to the lane's own predicate.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WAVE_ANY(p) (__ballot(p) != 0ull)
+#define RT_WAVE_COUNT(p) ((int)__popcll(__ballot(p)))
+#else
+#define RT_WAVE_ANY(p) (p)
+#define RT_WAVE_COUNT(p) ((p) ? 1 : 0)
+#endif
 
 struct LRay {     // ray in the current transform context + per-axis reciprocals (aabb.rs:146)
   V3 o, d, inv;
   uint32_t skip;  // bit k set: |d_k| < 1e-8, axis k is skipped by the slab test (aabb.rs:142-144)
+                  // bit 3 set: a component of o or d is not finite (compact quad records are not used then)
 };
 
 struct Hit {
   double t;
   uint32_t kind_idx;  // RTX_NODE_MAKE(SPHERE|QUAD|MEDIUM, table index); kind NONE = miss
   uint32_t ctx;       // transform context the hit was found in
-  double u, v;        // QUAD: alpha, beta.  MEDIUM with needs_uv: stale (u,v) of the record (constant_medium.rs:81-87)
 };
 
 // World -> context: apply the chain outermost first (translate.rs:37, rotate_y.rs:113-115).
@@ -72,20 +105,22 @@ RT_HD LRay lray_make(const Scene& S, uint32_t ctx, const V3& wo, const V3& wd) {
   if (ctx != 0) ctx_to_local(S, ctx, l.o, l.d);
   l.inv = v3(1.0 / l.d.x, 1.0 / l.d.y, 1.0 / l.d.z);
   l.skip = (fabs(l.d.x) < 1e-8 ? 1u : 0u) | (fabs(l.d.y) < 1e-8 ? 2u : 0u) | (fabs(l.d.z) < 1e-8 ? 4u : 0u);
+  const double mag = ((fabs(l.o.x) + fabs(l.o.y)) + fabs(l.o.z)) + ((fabs(l.d.x) + fabs(l.d.y)) + fabs(l.d.z));
+  if (!(mag < RT_INF)) l.skip |= 8u;
   return l;
 }
 
 // Aabb::hit, aabb.rs:132-167.  The per-axis early return is folded into one final comparison: the interval only
 // narrows, so it is empty at the end exactly when it was empty after some axis.
-RT_HD bool slab_hit(const rtx_aabb& b, const LRay& r, double tmin, double tmax) {
-  if (r.skip == 0) {
-    double t0 = (b.lo[0] - r.o.x) * r.inv.x, t1 = (b.hi[0] - r.o.x) * r.inv.x;
+RT_HD bool slab_hit(const double* b, const LRay& r, double tmin, double tmax) {  // b: lo[3], hi[3]
+  if ((r.skip & 7u) == 0) {
+    double t0 = (b[0] - r.o.x) * r.inv.x, t1 = (b[3] - r.o.x) * r.inv.x;
     bool pos = r.inv.x >= 0.0;
     tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    t0 = (b.lo[1] - r.o.y) * r.inv.y; t1 = (b.hi[1] - r.o.y) * r.inv.y;
+    t0 = (b[1] - r.o.y) * r.inv.y; t1 = (b[4] - r.o.y) * r.inv.y;
     pos = r.inv.y >= 0.0;
     tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    t0 = (b.lo[2] - r.o.z) * r.inv.z; t1 = (b.hi[2] - r.o.z) * r.inv.z;
+    t0 = (b[2] - r.o.z) * r.inv.z; t1 = (b[5] - r.o.z) * r.inv.z;
     pos = r.inv.z >= 0.0;
     tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
     return !(tmax <= tmin);
@@ -93,7 +128,7 @@ RT_HD bool slab_hit(const rtx_aabb& b, const LRay& r, double tmin, double tmax) 
   const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
   for (int a = 0; a < 3; ++a) {
     if (r.skip & (1u << a)) continue;
-    double t0 = (b.lo[a] - o[a]) * inv[a], t1 = (b.hi[a] - o[a]) * inv[a];
+    double t0 = (b[a] - o[a]) * inv[a], t1 = (b[3 + a] - o[a]) * inv[a];
     bool pos = inv[a] >= 0.0;
     tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
     if (tmax <= tmin) return false;
@@ -121,8 +156,7 @@ RT_HD bool sphere_hit_t(const rtx_sphere& s, const V3& o, const V3& d, double ti
 }
 
 // Quad::hit, quad.rs:66-86 (plane test, interval, interior test).
-RT_HD bool quad_hit_t(const rtx_quad& q, const V3& o, const V3& d, double tmin, double tmax, double& t, double& alpha,
-                      double& beta) {
+RT_HD bool quad_hit_t(const rtx_quad& q, const V3& o, const V3& d, double tmin, double tmax, double& t) {
   V3 n = v3(q.normal);
   double denom = dot(n, d);
   if (fabs(denom) < 1e-8) return false;
@@ -134,8 +168,53 @@ RT_HD bool quad_hit_t(const rtx_quad& q, const V3& o, const V3& d, double tmin, 
   double a = dot(w, cross(planar, v3(q.v)));
   double b = dot(w, cross(v3(q.u), planar));
   if (!(0.0 <= a && a <= 1.0) || !(0.0 <= b && b <= 1.0)) return false;
-  t = tt; alpha = a; beta = b;
+  t = tt;
   return true;
+}
+// Sphere::hit for a static sphere from its compact record: centre = c0 + 0*time = c0 (sphere.rs:84-104).
+RT_HD bool sphere_s_hit_t(const DSphere& s, const V3& o, const V3& d, double tmin, double tmax, double& t) {
+  V3 oc = o - v3(s.cx, s.cy, s.cz);
+  double a = norm2(d);
+  double half_b = dot(oc, d);
+  double c = norm2(oc) - s.r * s.r;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return false;
+  double sqrtd = sqrt(disc);
+  double root = (-half_b - sqrtd) / a;
+  if (!(tmin < root && root < tmax)) {
+    root = (-half_b + sqrtd) / a;
+    if (!(tmin < root && root < tmax)) return false;
+  }
+  t = root;
+  return true;
+}
+
+// Quad::hit (quad.rs:66-86) for a quad whose unit normal is exactly +-e_k, for a ray with finite components.  Every
+// product with an exact zero of normal / w drops out of the reference's dot products without changing their value,
+// so t is bit-identical and the interior test decides identically (alpha, beta can differ in the sign of a zero).
+RT_HD bool aaquad_hit_t(const DAAQuad& q, const V3& o, const V3& d, double tmin, double tmax, double& t) {
+  double ok, dk, oa, da, ob, db;
+  if (q.axis == 0) { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
+  else if (q.axis == 1) { ok = o.y; dk = d.y; oa = o.z; da = d.z; ob = o.x; db = d.x; }
+  else { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+  double denom = q.nk * dk;
+  if (fabs(denom) < 1e-8) return false;
+  double tt = (q.d - q.nk * ok) / denom;
+  if (!(tmin <= tt && tt <= tmax)) return false;
+  double pa = (oa + da * tt) - q.qa, pb = (ob + db * tt) - q.qb;
+  double alpha = q.wk * (pa * q.vb - pb * q.va);
+  double beta = q.wk * (q.ua * pb - q.ub * pa);
+  if (!(0.0 <= alpha && alpha <= 1.0) || !(0.0 <= beta && beta <= 1.0)) return false;
+  t = tt;
+  return true;
+}
+
+// The (alpha, beta) Quad::hit stores as (u, v) (quad.rs:81-82, 59-60) for the accepted point p.
+RT_HD void quad_uv(const rtx_quad& q, const V3& p, double& u, double& v) {
+  V3 planar = p - v3(q.q);
+  V3 w = v3(q.w);
+  u = dot(w, cross(planar, v3(q.v)));
+  v = dot(w, cross(v3(q.u), planar));
 }
 
 // sphere.rs:57-66
@@ -146,84 +225,199 @@ RT_HD void sphere_uv(const V3& p, double& u, double& v) {
   v = theta / RT_PI;
 }
 
-// (u,v) the reference's HitRecord would carry for a SPHERE/QUAD hit.
-RT_HD void hit_uv(const Scene& S, const Ray& wray, const Hit& h, double& u, double& v) {
-  uint32_t kind = RTX_NODE_KIND(h.kind_idx), idx = RTX_NODE_IDX(h.kind_idx);
-  if (kind == RTX_NODE_QUAD) { u = h.u; v = h.v; return; }
-  if (kind == RTX_NODE_SPHERE) {
-    V3 o = wray.o, d = wray.d;
-    if (h.ctx != 0) ctx_to_local(S, h.ctx, o, d);
+// (u,v) the reference's HitRecord carries for a SPHERE/QUAD hit at parameter t.
+RT_HD void hit_uv(const Scene& S, const Ray& wray, uint32_t kind_idx, uint32_t ctx, double t, double& u, double& v) {
+  const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx);
+  V3 o = wray.o, d = wray.d;
+  if (ctx != 0) ctx_to_local(S, ctx, o, d);
+  V3 p = ray_at(o, d, t);
+  if (kind == RTX_NODE_QUAD) {
+    quad_uv(S.quads[idx], p, u, v);
+  } else if (kind == RTX_NODE_SPHERE) {
     const rtx_sphere s = S.spheres[idx];
     V3 center = v3(s.c0) + v3(s.dc) * wray.tm;
-    V3 outward = (ray_at(o, d, h.t) - center) / s.radius;
-    sphere_uv(outward, u, v);
-    return;
+    sphere_uv((p - center) / s.radius, u, v);
   }
-  u = h.u; v = h.v;
 }
 
-// Closest hit of the program nodes[begin,end) for the world-space ray `wray`, starting in transform context ctx0.
-// MEDIA = false skips ConstantMedium nodes (used for medium boundaries and for the deterministic first-hit AOV).
-// `rng`/`bounce` address the medium free-path draws; the draw for a medium node uses that node's index as counter.
-template <bool MEDIA>
-RT_HD bool closest_hit(const Scene& S, uint32_t begin, uint32_t end, const Ray& wray, uint32_t ctx0, double tmin,
-                       double tmax, Hit& best, const PathRng* rng, uint32_t bounce) {
-  uint32_t cur = ctx0;
-  LRay lr = lray_make(S, cur, wray.o, wray.d);
-  bool found = false;
+// Where the traversal gets the world-space ray from when it has to rebuild the local ray (at program start, at
+// ENTER/EXIT nodes, for the stale (u,v)).  Keeping the world ray in registers for the whole walk costs 12 VGPRs;
+// the wavefront kernels re-read it from the path queue instead.
+struct RayRegs {
+  Ray r;
+  RT_HD V3 origin() const { return r.o; }
+  RT_HD V3 dir() const { return r.d; }
+};
+struct RayMem {       // structure-of-arrays queue: f[k*cap], k = 0..5
+  const double* f;
+  size_t cap;
+  RT_HD V3 origin() const { return v3(f[0], f[cap], f[2 * cap]); }
+  RT_HD V3 dir() const { return v3(f[3 * cap], f[4 * cap], f[5 * cap]); }
+};
+
+// Closest hit of the compiled program starting at unit `begin` (it runs until its END unit) for the world-space ray
+// `rs` (time `tm`) over [tmin0, tmax0], starting in the world context.  Returns kind NONE in best.kind_idx on a miss.
+// `active` false = this lane has no ray (it only takes part in the wave votes).
+//
+// Scheduling.  Each lane walks its own ray through the program, but the wave executes one KIND of step at a time:
+//   1. a tight loop of box tests runs while any lane stands on a box;
+//   2. lanes on other cheap units (filler, transform, program end, medium entry) take one step;
+//   3. once every lane stands on a primitive run, the wave votes and executes the primitive test most lanes wait
+//      for (static-sphere run, axis-aligned-quad run, general sphere/quad, medium free-path draw); the other lanes
+//      keep their place;
+//   4. a SYNC unit (placed by the program compiler between the top-level sections of the world) holds a lane until
+//      every lane of the wave has reached it, so that the section that follows runs in lockstep.
+// Lanes therefore share each expensive instruction stream instead of serialising sphere, quad and medium code in
+// every trip.  The order of steps within one ray is untouched, so results do not depend on the schedule.
+//
+// MEDIA = false skips ConstantMedium nodes (the deterministic first-hit AOV).  With MEDIA, a medium node runs its
+// boundary program twice through this same loop (constant_medium.rs:47-57: entry over the whole line, exit after
+// entry + 1e-4) by saving the outer query in a few registers instead of calling itself; boundaries never contain
+// media (checked when the scene is created).  The free-path draw of a medium uses the medium's table index as RNG
+// counter, so it does not depend on how paths are scheduled.  stale_uv (2 doubles, may be null) receives the
+// (u,v) the reference's record still holds when a medium whose phase texture reads them scatters
+// (constant_medium.rs:81-87 leaves u,v untouched).
+template <bool MEDIA, class RaySrc>
+RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
+                       double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
+                       double* stale_uv) {
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6 };
+  uint32_t cur = 0;
+  LRay lr;
+  lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  if (active) lr = lray_make(S, 0, rs.origin(), rs.dir());
   uint32_t i = begin;
-  while (i < end) {
-    const rtx_node nd = S.nodes[i];
-    const uint32_t kind = RTX_NODE_KIND(nd.kind_idx), idx = RTX_NODE_IDX(nd.kind_idx);
-    if (kind == RTX_NODE_BOX) {
-      i = slab_hit(S.boxes[idx], lr, tmin, tmax) ? i + 1 : nd.skip;
-      continue;
+  double tmin = tmin0, tmax = tmax0;
+  uint32_t hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0;
+  // state of the enclosing query while a medium boundary program runs
+  int mode = 0;  // 0: world program, 1: boundary entry query, 2: boundary exit query
+  uint32_t ret_i = 0, ret_cur = 0, out_kind = 0, out_ctx = 0, med = 0;
+  double out_tmax = 0.0, t_entry = 0.0;
+  bool running = active;
+  uint64_t unit = running ? prog[i] : (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  while (RT_WAVE_ANY(running)) {
+    // 1. boxes
+    while (RT_WAVE_ANY(running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX)) {
+      if (running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX) {
+        i = slab_hit((const double*)(prog + i + 2), lr, tmin, tmax) ? i + PROG_BOX_UNITS : (uint32_t)(unit >> 32);
+        unit = prog[i];
+      }
     }
-    if (kind == RTX_NODE_QUAD) {
-      double t, a, b;
-      if (quad_hit_t(S.quads[idx], lr.o, lr.d, tmin, tmax, t, a, b)) {
-        found = true; tmax = t;
-        best.t = t; best.kind_idx = nd.kind_idx; best.ctx = cur; best.u = a; best.v = b;
+    const uint32_t kind_idx = (uint32_t)unit;
+    const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
+    int cls = CL_CHEAP;
+    if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    else if (kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
+    else if (kind == RTX_NODE_SPHERE) cls = CL_SPHERE;
+    else if (kind == RTX_NODE_QUAD) cls = CL_QUAD;
+    else if (kind == PROG_NODE_SYNC) cls = CL_SYNC;
+    else if (MEDIA && kind == PROG_NODE_END && mode == 2 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) cls = CL_MEDIUM_EVAL;
+    uint32_t next = i;  // unit to stand on after this trip
+    if (RT_WAVE_ANY(running && cls == CL_CHEAP)) {
+      // 2. other cheap units
+      if (running && cls == CL_CHEAP) {
+        if (kind == PROG_NODE_END) {
+          if (!MEDIA || mode == 0) {
+            running = false;
+          } else if (mode == 1 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) {  // entry found at tmax: look for the exit
+            t_entry = tmax;
+            mode = 2; next = S.media[med].b_begin; tmin = t_entry + 0.0001; tmax = RT_INF;
+            hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
+          } else {                                                             // boundary missed: resume the world
+            mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
+          }
+        } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+          cur = idx;
+          lr = lray_make(S, cur, rs.origin(), rs.dir());
+          next = i + 1;
+        } else if (MEDIA && kind == RTX_NODE_MEDIUM && use_media) {
+          // save the enclosing query, run the boundary program from this context over the whole line
+          med = idx; ret_i = i + 1; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
+          mode = 1; next = S.media[idx].b_begin; tmin = -RT_INF; tmax = RT_INF;
+          hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
+        } else if (kind != RTX_NODE_BOX) {
+          next = i + 1;  // NOP filler, or a medium the query ignores
+        }
       }
-    } else if (kind == RTX_NODE_SPHERE) {
-      double t;
-      if (sphere_hit_t(S.spheres[idx], lr.o, lr.d, wray.tm, tmin, tmax, t)) {
-        found = true; tmax = t;
-        best.t = t; best.kind_idx = nd.kind_idx; best.ctx = cur; best.u = 0.0; best.v = 0.0;
-      }
-    } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
-      cur = idx;
-      lr = lray_make(S, cur, wray.o, wray.d);
-    } else if (MEDIA && kind == RTX_NODE_MEDIUM) {
-      if (rng != nullptr) {
-        const rtx_medium m = S.media[idx];
-        Hit h1, h2;
-        // constant_medium.rs:47-57: entry over the whole line, exit after entry + 1e-4
-        if (closest_hit<false>(S, m.b_begin, m.b_end, wray, cur, -RT_INF, RT_INF, h1, nullptr, 0) &&
-            closest_hit<false>(S, m.b_begin, m.b_end, wray, cur, h1.t + 0.0001, RT_INF, h2, nullptr, 0)) {
-          double t1 = fmax(h1.t, tmin);                       // 60
-          double t2 = fmin(h2.t, tmax);                       // 61
-          if (!(t1 >= t2)) {                                  // 63-65
-            t1 = fmax(t1, 0.0);                               // 67
-            double ray_length = norm(lr.d);                   // 70
-            double inside = (t2 - t1) * ray_length;           // 71
-            double xi = rng_at(*rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), i);
-            double hit_distance = m.neg_inv_density * log(xi);  // 74
-            if (!(hit_distance > inside)) {                   // 76-78
-              double t = t1 + hit_distance / ray_length;      // 81
-              double su = 0.0, sv = 0.0;
-              if (m.needs_uv && found) hit_uv(S, wray, best, su, sv);
-              found = true; tmax = t;
-              best.t = t; best.kind_idx = nd.kind_idx; best.ctx = cur; best.u = su; best.v = sv;
+    } else {
+      // 3. every running lane stands on a primitive (or waits at a SYNC): run the class most lanes wait for
+      const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
+      const int n_s = RT_WAVE_COUNT(running && cls == CL_SPHERE), n_q = RT_WAVE_COUNT(running && cls == CL_QUAD);
+      const int n_m = RT_WAVE_COUNT(running && cls == CL_MEDIUM_EVAL);
+      int pick = CL_SYNC, best_n = 0;
+      if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
+      if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+      if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
+      if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
+      if (n_m > best_n) { pick = CL_MEDIUM_EVAL; best_n = n_m; }
+      if (pick == CL_SYNC) {
+        // 4. everybody waits at a SYNC: pass it together
+        if (running && cls == CL_SYNC) next = i + 1;
+      } else if (pick == CL_SPHERE_S) {
+        if (running && cls == CL_SPHERE_S) {
+          for (uint32_t k = 0; k < count; ++k) {
+            double t;
+            if (sphere_s_hit_t(S.dspheres[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1;
+        }
+      } else if (pick == CL_QUAD_AA) {
+        if (running && cls == CL_QUAD_AA) {
+          for (uint32_t k = 0; k < count; ++k) {
+            double t;
+            if (aaquad_hit_t(S.daaquads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1;
+        }
+      } else if (pick == CL_SPHERE) {
+        if (running && cls == CL_SPHERE) {
+          double t;
+          if (sphere_hit_t(S.spheres[idx], lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
+          next = i + 1;
+        }
+      } else if (pick == CL_QUAD) {
+        if (running && cls == CL_QUAD) {  // a general quad, or a compact run met by a ray with non-finite components
+          const uint32_t cnt = kind == PROG_NODE_QUAD_AA ? count : 1u;
+          for (uint32_t k = 0; k < cnt; ++k) {
+            double t;
+            if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1;
+        }
+      } else if (MEDIA) {
+        if (running && cls == CL_MEDIUM_EVAL) {      // constant_medium.rs:60-87, exit found at tmax
+          const rtx_medium m = S.media[med];
+          double t1 = fmax(t_entry, tmin0);
+          double t2 = fmin(tmax, out_tmax);
+          if (!(t1 >= t2)) {
+            t1 = fmax(t1, 0.0);
+            double ray_length = norm(lr.d);
+            double inside = (t2 - t1) * ray_length;
+            double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
+            double hit_distance = m.neg_inv_density * log(xi);
+            if (!(hit_distance > inside)) {
+              if (m.needs_uv && stale_uv) {
+                stale_uv[0] = 0.0; stale_uv[1] = 0.0;
+                if (RTX_NODE_KIND(out_kind) == RTX_NODE_SPHERE || RTX_NODE_KIND(out_kind) == RTX_NODE_QUAD) {
+                  Ray w;
+                  w.o = rs.origin(); w.d = rs.dir(); w.tm = tm;
+                  hit_uv(S, w, out_kind, out_ctx, out_tmax, stale_uv[0], stale_uv[1]);
+                }
+              }
+              out_tmax = t1 + hit_distance / ray_length;
+              out_kind = RTX_NODE_MAKE(RTX_NODE_MEDIUM, med); out_ctx = ret_cur;
             }
           }
+          mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
         }
       }
     }
-    ++i;
+    if (running && next != i) { i = next; unit = prog[i]; }
   }
-  return found;
+  best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
 }
+
+RT_HD bool hit_any(const Hit& h) { return RTX_NODE_KIND(h.kind_idx) != RTX_NODE_NONE; }
 
 // What the integrator needs from a hit: the fields of HitRecord (hittable.rs:9-17) in world space.
 struct Surface {
@@ -235,12 +429,12 @@ struct Surface {
 
 // Rebuild the HitRecord for `h`: same expressions, in the hit's own context, then carried out through the enclosing
 // transforms (sphere.rs:106-115, quad.rs:88-92, constant_medium.rs:81-87, rotate_y.rs:123-124, translate.rs:45).
-RT_HD void resolve_hit(const Scene& S, const Ray& wray, const Hit& h, bool want_uv, Surface& sf) {
+RT_HD void resolve_hit(const Scene& S, const Ray& wray, const Hit& h, bool want_uv, const double* stale_uv, Surface& sf) {
   const uint32_t kind = RTX_NODE_KIND(h.kind_idx), idx = RTX_NODE_IDX(h.kind_idx);
   V3 o = wray.o, d = wray.d;
   if (h.ctx != 0) ctx_to_local(S, h.ctx, o, d);
   sf.p = ray_at(o, d, h.t);
-  sf.u = h.u; sf.v = h.v;
+  sf.u = 0.0; sf.v = 0.0;
   if (kind == RTX_NODE_SPHERE) {
     const rtx_sphere s = S.spheres[idx];
     V3 center = v3(s.c0) + v3(s.dc) * wray.tm;
@@ -252,6 +446,7 @@ RT_HD void resolve_hit(const Scene& S, const Ray& wray, const Hit& h, bool want_
   } else if (kind == RTX_NODE_QUAD) {
     const rtx_quad q = S.quads[idx];
     V3 n = v3(q.normal);
+    if (want_uv) quad_uv(q, sf.p, sf.u, sf.v);
     sf.front = dot(d, n) < 0.0;
     sf.n = sf.front ? n : -n;
     sf.mat = q.mat; sf.prim_id = q.prim_id;
@@ -259,6 +454,7 @@ RT_HD void resolve_hit(const Scene& S, const Ray& wray, const Hit& h, bool want_
     sf.n = v3(1.0, 0.0, 0.0);
     sf.front = true;
     sf.mat = S.media[idx].mat; sf.prim_id = 0xFFFFFFFEu;
+    if (want_uv && stale_uv) { sf.u = stale_uv[0]; sf.v = stale_uv[1]; }
   }
   if (h.ctx != 0) ctx_to_world(S, h.ctx, sf.p, sf.n);
 }

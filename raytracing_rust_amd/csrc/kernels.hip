@@ -4,18 +4,200 @@
 // otherwise.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
 #include <vector>
 
 #include "../../include/rtx.h"
+#include "core/rt_program.h"
 #include "core/rt_shade.h"
 
 using namespace rt;
 
-// --------------------------------------------------------------- kernels ---
+// ================================================================ kernels ===
 
+// ------------------------------------------------------- wavefront state ---
+// Paths in flight live in structure-of-arrays queues so that every load and store of a wave is one contiguous run.
+// f[k*cap + slot], k = 0..9: ray origin (3), ray direction (3), ray time, throughput (3).
+// u[k*cap + slot], k = 0..2: pixel index, sample index, remaining depth << 16 | bounce.
+struct WfQueue {
+  double* f;
+  uint32_t* u;
+};
+struct WfHits {        // output of the traversal kernel, input of the shading kernel
+  double* t;           // hit parameter
+  uint32_t* kind_idx;  // RTX_NODE_MAKE(kind, index); kind NONE = miss
+  uint32_t* ctx;       // transform context of the hit
+  double* uv;          // [2*cap]: the stale record (u,v) of a medium hit whose phase texture reads them; rarely written
+};
+struct WfCounters {
+  uint32_t n_in;        // paths in the queue the traversal/shading kernels read
+  uint32_t n_out;       // survivors appended to the other queue by the shading kernel
+  uint32_t gen_count;   // camera paths to start in this iteration
+  uint32_t _pad;
+  unsigned long long gen_first, next_path, total_paths;
+};
+struct WfFrame {       // what a path index means: pixel rectangle in 8x8 tiles x sample range
+  int x0, y0, x1, y1, tiles_x, sample_begin;
+  unsigned long long per_sample;  // tiles * 64
+};
+
+__global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
+  c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_first = 0; c->next_path = 0; c->total_paths = total;
+}
+
+// One thread: decide how many new camera paths top the queue up and flip the in/out roles.
+__global__ void k_wf_prepare(WfCounters* c, uint32_t cap, unsigned long long* __restrict__ stats) {
+  const uint32_t survivors = c->n_out;
+  const unsigned long long remaining = c->total_paths - c->next_path;
+  const unsigned long long room = cap - survivors;
+  const uint32_t g = (uint32_t)(remaining < room ? remaining : room);
+  c->gen_count = g; c->gen_first = c->next_path; c->next_path += g;
+  c->n_in = survivors;  // the ray generation kernel appends the valid new paths behind the survivors
+  c->n_out = 0;
+  (void)stats;
+}
+
+// Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, 8x8 tile, pixel in tile), so that the 64
+// lanes of a wave start the same stratified sample of neighbouring pixels.  Valid paths are appended to the queue
+// with one atomic per wave.
+__global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame fr, unsigned long long seed, uint32_t cap,
+                                                   WfCounters* c, WfQueue q, unsigned long long* __restrict__ stats) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  bool valid = false;
+  int i = 0, j = 0, s = 0;
+  if (idx < c->gen_count) {
+    const unsigned long long p = c->gen_first + idx;
+    const unsigned long long so = p / fr.per_sample, rem = p % fr.per_sample;
+    const uint32_t tile = (uint32_t)(rem >> 6), l = (uint32_t)(rem & 63);
+    s = fr.sample_begin + (int)so;
+    i = fr.x0 + (int)(tile % (uint32_t)fr.tiles_x) * 8 + (int)(l & 7);
+    j = fr.y0 + (int)(tile / (uint32_t)fr.tiles_x) * 8 + (int)(l >> 3);
+    valid = i < fr.x1 && j < fr.y1 && cam.max_depth > 0;
+  }
+  const unsigned long long mask = __ballot(valid);
+  if (mask == 0) return;
+  uint32_t base = 0;
+  if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) {
+    base = atomicAdd(&c->n_in, (uint32_t)__popcll(mask));
+    atomicAdd(&stats[0], (unsigned long long)__popcll(mask));
+  }
+  base = __shfl(base, __ffsll((long long)mask) - 1);
+  if (!valid) return;
+  const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  const uint32_t pixel = (uint32_t)(j * cam.image_width + i);
+  PathRng rng = rng_make(seed, pixel, (uint32_t)s);
+  Ray r = camera_ray(cam, i, j, s, rng);
+  double* f = q.f + slot;
+  f[0 * (size_t)cap] = r.o.x; f[1 * (size_t)cap] = r.o.y; f[2 * (size_t)cap] = r.o.z;
+  f[3 * (size_t)cap] = r.d.x; f[4 * (size_t)cap] = r.d.y; f[5 * (size_t)cap] = r.d.z;
+  f[6 * (size_t)cap] = r.tm;
+  f[7 * (size_t)cap] = 1.0; f[8 * (size_t)cap] = 1.0; f[9 * (size_t)cap] = 1.0;
+  uint32_t* u = q.u + slot;
+  u[0] = pixel; u[(size_t)cap] = (uint32_t)s; u[2 * (size_t)cap] = (uint32_t)cam.max_depth << 16;
+}
+
+// Traversal kernel: one closest-hit query per queued path (world.hit, camera.rs:179).  Persistent 1024-thread
+// workgroups, one per CU: each stages the whole hit program (nodes + boxes) in LDS once, then walks its share of
+// the queue; only primitive records and the ray/hit streams touch global memory.
+template <bool USE_LDS>
+__global__ __launch_bounds__(1024) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, const WfCounters* c,
+                                                      WfQueue q, WfHits h, unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
+  const uint32_t n = c->n_in;
+  if (blockIdx.x * blockDim.x >= n) return;
+  const uint64_t* prog = S.prog;
+  if (USE_LDS) {
+    const uint4* src = (const uint4*)S.prog;
+    uint4* dst = (uint4*)lds_prog;
+    for (uint32_t k = threadIdx.x; k < S.n_units / 2; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    prog = lds_prog;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
+  // the trip count is the same for every lane of a wave: lanes past the end of the queue only vote
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t idx = base + threadIdx.x;
+    const bool active = idx < n;
+    const uint32_t ld = active ? idx : 0;
+    RayMem rs;
+    rs.f = q.f + ld; rs.cap = cap;
+    const double tm = rs.f[6 * (size_t)cap];
+    PathRng rng = rng_make(seed, 0, 0);
+    uint32_t bounce = 0;
+    if (S.n_media) {
+      const uint32_t* u = q.u + ld;
+      rng = rng_make(seed, u[0], u[(size_t)cap]);
+      bounce = u[2 * (size_t)cap] & 0xFFFFu;
+    }
+    Hit hit;
+    closest_hit<true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, S.n_media != 0, rng, bounce,
+                      h.uv + 2 * (size_t)ld);
+    if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
+  }
+}
+
+// Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
+// ends adds throughput x radiance to its pixel; a path that goes on is appended to the other queue, compacted with
+// one ballot and one atomic per wave, so dead lanes never reach the next traversal.
+__global__ __launch_bounds__(256) void k_wf_shade(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
+                                                  int use_lights, WfCounters* c, WfQueue qin, WfHits h, WfQueue qout,
+                                                  double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n = c->n_in;
+  if (blockIdx.x * blockDim.x >= n) return;
+  bool alive = false;
+  PathState ps;
+  Ray next;
+  uint32_t pixel = 0, sample = 0, probes = 0;
+  if (idx < n) {
+    const double* f = qin.f + idx;
+    Ray ray;
+    ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
+    ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
+    ray.tm = f[6 * (size_t)cap];
+    ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
+    ps.L = v3(0.0, 0.0, 0.0);
+    const uint32_t* u = qin.u + idx;
+    pixel = u[0]; sample = u[(size_t)cap];
+    const uint32_t db = u[2 * (size_t)cap];
+    ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
+    ps.rng = rng_make(seed, pixel, sample);
+    Hit hit;
+    hit.t = h.t[idx]; hit.kind_idx = h.kind_idx[idx]; hit.ctx = h.ctx[idx];
+    alive = shade_bounce(S, v3(cam.background), use_lights != 0, ray, hit, h.uv + 2 * (size_t)idx, ps, next, probes);
+    if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
+      double* a = accum + (size_t)pixel * 3;
+      unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
+    }
+  }
+  // light-probe statistics: one atomic per wave
+  uint32_t wp = probes;
+  for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
+  if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
+  // wave-ballot compaction of the survivors
+  const unsigned long long mask = __ballot(alive);
+  if (mask == 0) return;
+  const int leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if ((int)lane == leader) base = atomicAdd(&c->n_out, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (!alive) return;
+  const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  double* f = qout.f + slot;
+  f[0 * (size_t)cap] = next.o.x; f[1 * (size_t)cap] = next.o.y; f[2 * (size_t)cap] = next.o.z;
+  f[3 * (size_t)cap] = next.d.x; f[4 * (size_t)cap] = next.d.y; f[5 * (size_t)cap] = next.d.z;
+  f[6 * (size_t)cap] = next.tm;
+  f[7 * (size_t)cap] = ps.T.x; f[8 * (size_t)cap] = ps.T.y; f[9 * (size_t)cap] = ps.T.z;
+  uint32_t* u = qout.u + slot;
+  u[0] = pixel; u[(size_t)cap] = sample; u[2 * (size_t)cap] = ((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu);
+}
+
+// ------------------------------------------------------------ fused path ---
 // Fused path tracer: one lane owns one pixel and walks its samples one after another.  Every trip of the loop is
 // one segment for every lane of the wave (closest hit, then shading), so the wave stays in one phase; a lane whose
 // path ended starts its next sample in place (path regeneration), which keeps lanes busy without any path state in
@@ -38,23 +220,28 @@ __global__ __launch_bounds__(256) void k_render_fused(Scene S, rtx_camera_desc c
   PathState ps;
   Ray ray;
   ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.tm = 0;
+  path_begin(ps, 0, rng_make(o.seed, pixel, 0));
   for (;;) {
-    if (!alive) {
-      if (!inrect || s >= o.sample_end) break;
+    if (!alive && inrect && s < o.sample_end) {
       PathRng rng = rng_make(o.seed, pixel, (uint32_t)s);
       ray = camera_ray(cam, i, j, s, rng);
       path_begin(ps, cam.max_depth, rng);
       ++s; ++npaths;
       alive = ps.depth > 0;
-      if (!alive) continue;
     }
+    if (!__any(alive)) break;  // the wave leaves together: the traversal below votes across all 64 lanes
     Hit hit;
-    ++segs;
-    bool any = closest_hit<true>(S, S.world_begin, S.world_end, ray, 0, 0.001, RT_INF, hit, &ps.rng, ps.bounce);
-    Ray next;
-    alive = shade_bounce(S, bg, use_lights != 0, ray, any, hit, ps, next, probes);
-    ray = next;
-    if (!alive) sum = sum + ps.L;
+    double stale_uv[2] = {0.0, 0.0};
+    if (alive) ++segs;
+    RayRegs rs;
+    rs.r = ray;
+    closest_hit<true>(S, S.prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, true, ps.rng, ps.bounce, stale_uv);
+    if (alive) {
+      Ray next;
+      alive = shade_bounce(S, bg, use_lights != 0, ray, hit, stale_uv, ps, next, probes);
+      ray = next;
+      if (!alive) sum = sum + ps.L;
+    }
   }
   if (inrect) {
     double* a = accum + (size_t)pixel * 3;
@@ -72,15 +259,19 @@ __global__ __launch_bounds__(256) void k_render_fused(Scene S, rtx_camera_desc c
 __global__ __launch_bounds__(256) void k_first_hit(Scene S, const double* __restrict__ rays, size_t n, double* t,
                                                    double* normal, uint32_t* prim_id, uint32_t* mat_id, uint8_t* front) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
-  const double* r = rays + 7 * idx;
+  const bool active = idx < n;
+  const double* r = rays + 7 * (active ? idx : 0);
   Ray ray;
   ray.o = v3(r[0], r[1], r[2]); ray.d = v3(r[3], r[4], r[5]); ray.tm = r[6];
   Hit h;
-  bool any = closest_hit<false>(S, S.world_begin, S.world_end, ray, 0, 0.001, RT_INF, h, nullptr, 0);
+  RayRegs rs;
+  rs.r = ray;
+  closest_hit<false>(S, S.prog, S.world_begin, active, rs, ray.tm, 0.001, RT_INF, h, false, PathRng(), 0, nullptr);
+  if (!active) return;
+  const bool any = hit_any(h);
   Surface sf;
   sf.n = v3(0, 0, 0); sf.prim_id = 0xFFFFFFFFu; sf.mat = 0xFFFFFFFFu; sf.front = false;
-  if (any) resolve_hit(S, ray, h, false, sf);
+  if (any) resolve_hit(S, ray, h, false, nullptr, sf);
   if (t) t[idx] = any ? h.t : RT_INF;
   if (normal) { normal[3 * idx] = sf.n.x; normal[3 * idx + 1] = sf.n.y; normal[3 * idx + 2] = sf.n.z; }
   if (prim_id) prim_id[idx] = sf.prim_id;
@@ -93,24 +284,29 @@ __global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ accu
   if (idx < n) rgb[idx] = resolve_channel(accum[idx], scale);
 }
 
-__global__ __launch_bounds__(256) void k_add(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n) dst[idx] += src[idx];
-}
-
-// ------------------------------------------------------------------ host ---
+// =================================================================== host ===
 
 static thread_local std::string g_error;
 
+struct TimedSpan { hipEvent_t e0, e1; int what; };  // what: 0 = whole render call, 1 = traversal kernel
+
 struct rtx_context {
   int device = 0;
+  int n_cus = 256;
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
-  double render_ms = 0.0;
-  uint64_t launches = 0;
-  double last_kernel_ms = 0.0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // timed launches not yet read back
+  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0;
+  uint64_t launches = 0, traverse_launches = 0;
+  std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
+  // wavefront workspace (allocated on first use, kept for the context's lifetime)
+  uint32_t wf_cap = 0;
+  WfQueue wf_q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  WfHits wf_hits = {nullptr, nullptr, nullptr, nullptr};
+  WfCounters* wf_c = nullptr;
+  WfCounters* wf_host = nullptr;  // pinned, two slots
+  hipEvent_t wf_ev[2] = {nullptr, nullptr};
+  std::vector<void*> wf_allocs;
 };
 
 struct rtx_scene {
@@ -139,48 +335,23 @@ static hipEvent_t get_event(rtx_context* ctx) {
 static void drain_events(rtx_context* ctx) {
   for (auto& p : ctx->pending) {
     float ms = 0.f;
-    if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
-      ctx->render_ms += ms; ctx->last_kernel_ms = ms; ctx->launches += 1;
+    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      if (p.what == 0) { ctx->render_ms += ms; ctx->last_kernel_ms = ms; ctx->launches += 1; }
+      else { ctx->traverse_ms += ms; ctx->traverse_launches += 1; }
     }
-    ctx->free_events.push_back(p.first); ctx->free_events.push_back(p.second);
+    ctx->free_events.push_back(p.e0); ctx->free_events.push_back(p.e1);
   }
   ctx->pending.clear();
 }
-
-extern "C" {
-
-const char* rtx_last_error(const rtx_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
-
-rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context** out) {
-  if (!out) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: out is null");
-  *out = nullptr;
-  if (n_devices != 1) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: n_devices must be 1 (one context per process and GPU)");
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count < 1) return fail(nullptr, RTX_ERR_NO_DEVICE, "rtx_context_create: no HIP device available (this backend has no CPU path)");
-  int dev = device_ids ? device_ids[0] : 0;
-  if (dev < 0 || dev >= count) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: device id out of range");
-  rtx_context* ctx = new rtx_context();
-  ctx->device = dev;
-  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess) {
-    delete ctx;
-    return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
-  }
-  *out = ctx;
-  return RTX_OK;
+// Begin/end a timed span on `stream`; returns false when no event could be created (timing is then skipped).
+static bool span_begin(rtx_context* ctx, hipStream_t stream, TimedSpan& sp, int what) {
+  sp.e0 = get_event(ctx); sp.e1 = get_event(ctx); sp.what = what;
+  if (!sp.e0 || !sp.e1) return false;
+  return hipEventRecord(sp.e0, stream) == hipSuccess;
 }
-
-void rtx_context_destroy(rtx_context* ctx) {
-  if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
-  drain_events(ctx);
-  for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
-  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-  delete ctx;
+static void span_end(rtx_context* ctx, hipStream_t stream, TimedSpan& sp) {
+  if (hipEventRecord(sp.e1, stream) == hipSuccess) ctx->pending.push_back(sp);
 }
-
-}  // extern "C"
 
 static bool check_texture_depth(const rtx_scene_desc* d, uint32_t tex, int depth) {
   if (depth > RTX_MAX_TEXTURE_DEPTH) return false;
@@ -198,6 +369,7 @@ static const char* validate_scene(const rtx_scene_desc* d) {
       (d->n_textures && !d->textures) || (d->n_images && !d->images) || (d->n_texel_bytes && !d->texels) ||
       (d->n_perlins && !d->perlins) || (d->n_lights && !d->lights))
     return "null table with a non-zero count";
+  if (d->n_nodes >= (1u << 28)) return "more than 2^28 nodes";
   for (uint32_t i = 0; i < d->n_xforms; ++i)
     if ((uint64_t)d->xforms[i].first_op + d->xforms[i].n_ops > d->n_xform_ops) return "xform op range out of bounds";
   for (uint32_t i = 0; i < d->n_xform_ops; ++i)
@@ -234,12 +406,21 @@ static const char* validate_scene(const rtx_scene_desc* d) {
     for (uint32_t k = m.b_begin; k < m.b_end; ++k)
       if (RTX_NODE_KIND(d->nodes[k].kind_idx) == RTX_NODE_MEDIUM) return "medium inside a medium boundary";
   }
+  // a box may only skip forward, and never out of the program (world or medium boundary) it belongs to
+  for (uint32_t r = 0; r <= d->n_media; ++r) {
+    const uint32_t b = r == 0 ? d->world_begin : d->media[r - 1].b_begin, e = r == 0 ? d->world_end : d->media[r - 1].b_end;
+    for (uint32_t i = b; i < e; ++i)
+      if (RTX_NODE_KIND(d->nodes[i].kind_idx) == RTX_NODE_BOX && (d->nodes[i].skip <= i || d->nodes[i].skip > e))
+        return "box skip link must point forward inside its program";
+    if (r > 0)
+      for (uint32_t i = b; i < e; ++i)
+        if (RTX_NODE_KIND(d->nodes[i].kind_idx) == RTX_NODE_MEDIUM) return "medium inside a medium boundary";
+  }
   for (uint32_t i = 0; i < d->n_nodes; ++i) {
     const uint32_t kind = RTX_NODE_KIND(d->nodes[i].kind_idx), idx = RTX_NODE_IDX(d->nodes[i].kind_idx);
     switch (kind) {
       case RTX_NODE_BOX:
         if (idx >= d->n_boxes) return "box index out of range";
-        if (d->nodes[i].skip <= i || d->nodes[i].skip > d->n_nodes) return "box skip link must point forward inside nodes";
         break;
       case RTX_NODE_SPHERE: if (idx >= d->n_spheres) return "sphere index out of range"; break;
       case RTX_NODE_QUAD: if (idx >= d->n_quads) return "quad index out of range"; break;
@@ -270,20 +451,149 @@ static rtx_status upload(rtx_scene* sc, const T* src, size_t count, const T** ds
   return RTX_OK;
 }
 
+static const char* validate_render(const rtx_camera_desc* cam, const rtx_render_opts* o) {
+  if (cam->image_width < 1 || cam->image_height < 1 || cam->sqrt_spp < 1) return "camera not initialised (call rtx_camera_initialize)";
+  if ((int64_t)cam->image_width * cam->image_height > 0x7FFFFFFF / 4) return "image too large";
+  if (o->x0 < 0 || o->y0 < 0 || o->x1 > cam->image_width || o->y1 > cam->image_height || o->x0 > o->x1 || o->y0 > o->y1) return "pixel rectangle outside the image";
+  if (o->sample_begin < 0 || o->sample_begin > o->sample_end || o->sample_end > cam->sqrt_spp * cam->sqrt_spp) return "sample range outside [0, sqrt_spp^2]";
+  if (o->pipeline < RTX_PIPELINE_DEFAULT || o->pipeline > RTX_PIPELINE_WAVEFRONT) return "unknown pipeline";
+  return nullptr;
+}
+
+static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, one persistent workgroup per CU
+
+static rtx_status wf_ensure(rtx_context* ctx) {
+  if (ctx->wf_cap) return RTX_OK;
+  uint32_t cap = 1u << 21;
+  if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
+  cap = (cap + 255u) & ~255u;
+  auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) ctx->wf_allocs.push_back(*p); return e; };
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(ctx, A((void**)&ctx->wf_q[k].f, (size_t)cap * 10 * sizeof(double)));
+    HIP_TRY(ctx, A((void**)&ctx->wf_q[k].u, (size_t)cap * 3 * sizeof(uint32_t)));
+  }
+  HIP_TRY(ctx, A((void**)&ctx->wf_hits.t, (size_t)cap * sizeof(double)));
+  HIP_TRY(ctx, A((void**)&ctx->wf_hits.kind_idx, (size_t)cap * sizeof(uint32_t)));
+  HIP_TRY(ctx, A((void**)&ctx->wf_hits.ctx, (size_t)cap * sizeof(uint32_t)));
+  HIP_TRY(ctx, A((void**)&ctx->wf_hits.uv, (size_t)cap * 2 * sizeof(double)));
+  HIP_TRY(ctx, A((void**)&ctx->wf_c, sizeof(WfCounters)));
+  HIP_TRY(ctx, hipHostMalloc((void**)&ctx->wf_host, 2 * sizeof(WfCounters), hipHostMallocDefault));
+  for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[k], hipEventDisableTiming));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  ctx->wf_cap = cap;
+  return RTX_OK;
+}
+
+// The wavefront loop: [prepare, ray generation, traversal, shading+compaction] per iteration until every camera path
+// of the call has ended.  Iterations are enqueued in chunks; the counters of chunk k are inspected while chunk k+1 is
+// already enqueued, so the GPU never waits for the host.  Kernels of an iteration with nothing to do exit at once.
+static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
+  rtx_context* ctx = sc->ctx;
+  rtx_status st = wf_ensure(ctx);
+  if (st != RTX_OK) return st;
+  const uint32_t cap = ctx->wf_cap;
+  WfFrame fr;
+  fr.x0 = o->x0; fr.y0 = o->y0; fr.x1 = o->x1; fr.y1 = o->y1; fr.sample_begin = o->sample_begin;
+  fr.tiles_x = (o->x1 - o->x0 + 7) / 8;
+  const int tiles_y = (o->y1 - o->y0 + 7) / 8;
+  fr.per_sample = (unsigned long long)fr.tiles_x * (unsigned long long)tiles_y * 64ull;
+  const unsigned long long total = fr.per_sample * (unsigned long long)(o->sample_end - o->sample_begin);
+  const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
+  const size_t prog_bytes = (size_t)sc->dev.n_units * 8;
+  const bool use_lds = prog_bytes <= kLdsBudget;
+  const unsigned blocks256 = cap / 256;
+  const unsigned trav_blocks = (unsigned)ctx->n_cus;
+  hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, stream, ctx->wf_c, total);
+  const int chunk = 8;
+  int cur = 0;  // queue the traversal reads in the next iteration
+  bool done = false;
+  for (int k = 0; !done; ++k) {
+    for (int it = 0; it < chunk; ++it) {
+      WfQueue qin = ctx->wf_q[cur], qout = ctx->wf_q[cur ^ 1];
+      hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, stream, ctx->wf_c, cap, ctx->d_counters);
+      hipLaunchKernelGGL(k_wf_raygen, dim3(blocks256), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin, ctx->d_counters);
+      TimedSpan sp;
+      const bool timed = span_begin(ctx, stream, sp, 1);
+      if (use_lds)
+        hipLaunchKernelGGL(k_wf_traverse<true>, dim3(trav_blocks), dim3(1024), prog_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+      else
+        hipLaunchKernelGGL(k_wf_traverse<false>, dim3(trav_blocks), dim3(1024), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+      if (timed) span_end(ctx, stream, sp);
+      hipLaunchKernelGGL(k_wf_shade, dim3(blocks256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
+      cur ^= 1;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(&ctx->wf_host[k & 1], ctx->wf_c, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[k & 1], stream));
+    if (k > 0) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->wf_ev[(k - 1) & 1]));
+      const WfCounters& c = ctx->wf_host[(k - 1) & 1];
+      done = c.n_out == 0 && c.next_path == c.total_paths;
+    }
+    if (ctx->pending.size() > 2048) drain_events(ctx);
+  }
+  return RTX_OK;
+}
+
 extern "C" {
+
+const char* rtx_last_error(const rtx_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
+
+rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context** out) {
+  if (!out) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: out is null");
+  *out = nullptr;
+  if (n_devices != 1) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: n_devices must be 1 (one context per process and GPU)");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count < 1) return fail(nullptr, RTX_ERR_NO_DEVICE, "rtx_context_create: no HIP device available (this backend has no CPU path)");
+  int dev = device_ids ? device_ids[0] : 0;
+  if (dev < 0 || dev >= count) return fail(nullptr, RTX_ERR_INVALID, "rtx_context_create: device id out of range");
+  rtx_context* ctx = new rtx_context();
+  ctx->device = dev;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
+  }
+  ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = ctx;
+  return RTX_OK;
+}
+
+void rtx_context_destroy(rtx_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  drain_events(ctx);
+  for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+  for (void* p : ctx->wf_allocs) (void)hipFree(p);
+  if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
+  for (int k = 0; k < 2; ++k) if (ctx->wf_ev[k]) (void)hipEventDestroy(ctx->wf_ev[k]);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  delete ctx;
+}
 
 rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene** out) {
   if (!ctx || !d || !out) return fail(ctx, RTX_ERR_INVALID, "rtx_scene_create: null argument");
   *out = nullptr;
   if (const char* why = validate_scene(d)) return fail(ctx, RTX_ERR_INVALID, std::string("rtx_scene_create: ") + why);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  CompiledProgram prog;
+  prog.compile(*d);
   rtx_scene* sc = new rtx_scene();
   sc->ctx = ctx;
-  sc->dev = *d;
-  rtx_status st = RTX_OK;
+  static_cast<rtx_scene_desc&>(sc->dev) = *d;
+  sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
+  sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
+  sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev._pad1 = 0;
+  rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
+  if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
+  if (st == RTX_OK) st = upload(sc, prog.dspheres.data(), prog.dspheres.size(), &sc->dev.dspheres);
+  if (st == RTX_OK) st = upload(sc, prog.daaquads.data(), prog.daaquads.size(), &sc->dev.daaquads);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
-  UP(nodes, d->n_nodes); UP(boxes, d->n_boxes); UP(spheres, d->n_spheres); UP(quads, d->n_quads);
-  UP(xforms, d->n_xforms); UP(xform_ops, d->n_xform_ops); UP(media, d->n_media); UP(materials, d->n_materials);
+  UP(boxes, d->n_boxes); UP(spheres, d->n_spheres); UP(quads, d->n_quads);
+  UP(xforms, d->n_xforms); UP(xform_ops, d->n_xform_ops); UP(materials, d->n_materials);
   UP(textures, d->n_textures); UP(images, d->n_images); UP(texels, d->n_texel_bytes); UP(perlins, d->n_perlins);
   UP(lights, d->n_lights);
 #undef UP
@@ -300,19 +610,6 @@ void rtx_scene_destroy(rtx_scene* sc) {
   delete sc;
 }
 
-}  // extern "C"
-
-static const char* validate_render(const rtx_camera_desc* cam, const rtx_render_opts* o) {
-  if (cam->image_width < 1 || cam->image_height < 1 || cam->sqrt_spp < 1) return "camera not initialised (call rtx_camera_initialize)";
-  if ((int64_t)cam->image_width * cam->image_height > 0x7FFFFFFF / 4) return "image too large";
-  if (o->x0 < 0 || o->y0 < 0 || o->x1 > cam->image_width || o->y1 > cam->image_height || o->x0 > o->x1 || o->y0 > o->y1) return "pixel rectangle outside the image";
-  if (o->sample_begin < 0 || o->sample_begin > o->sample_end || o->sample_end > cam->sqrt_spp * cam->sqrt_spp) return "sample range outside [0, sqrt_spp^2]";
-  if (o->pipeline < RTX_PIPELINE_DEFAULT || o->pipeline > RTX_PIPELINE_WAVEFRONT) return "unknown pipeline";
-  return nullptr;
-}
-
-extern "C" {
-
 rtx_status rtx_render_device(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, void* hip_stream) {
   if (!sc || !cam || !o || !accum_dev) return fail(sc ? sc->ctx : nullptr, RTX_ERR_INVALID, "rtx_render_device: null argument");
   rtx_context* ctx = sc->ctx;
@@ -320,17 +617,26 @@ rtx_status rtx_render_device(rtx_scene* sc, const rtx_camera_desc* cam, const rt
   if (o->x0 == o->x1 || o->y0 == o->y1 || o->sample_begin == o->sample_end) return RTX_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t)hip_stream;
-  const int tiles_x = (o->x1 - o->x0 + 15) / 16, tiles_y = (o->y1 - o->y0 + 15) / 16;
-  const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
-  hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-  if (!e0 || !e1) return fail(ctx, RTX_ERR_HIP, "rtx_render_device: hipEventCreate failed");
-  HIP_TRY(ctx, hipEventRecord(e0, stream));
-  hipLaunchKernelGGL(k_render_fused, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, stream, sc->dev, *cam, *o, use_lights, accum_dev, ctx->d_counters);
-  HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(e1, stream));
-  ctx->pending.emplace_back(e0, e1);
+  int pipeline = o->pipeline;
+  if (pipeline == RTX_PIPELINE_DEFAULT) {
+    const char* e = getenv("RTX_PIPELINE");
+    pipeline = (e && atoi(e) == RTX_PIPELINE_FUSED) ? RTX_PIPELINE_FUSED : RTX_PIPELINE_WAVEFRONT;
+  }
+  if (cam->max_depth > 0xFFFF) pipeline = RTX_PIPELINE_FUSED;  // the wavefront state packs depth and bounce into 16 bits each
+  TimedSpan sp;
+  const bool timed = span_begin(ctx, stream, sp, 0);
+  rtx_status st = RTX_OK;
+  if (pipeline == RTX_PIPELINE_FUSED) {
+    const int tiles_x = (o->x1 - o->x0 + 15) / 16, tiles_y = (o->y1 - o->y0 + 15) / 16;
+    const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
+    hipLaunchKernelGGL(k_render_fused, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, stream, sc->dev, *cam, *o, use_lights, accum_dev, ctx->d_counters);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    st = render_wavefront(sc, cam, o, accum_dev, stream);
+  }
+  if (timed) span_end(ctx, stream, sp);
   if (ctx->pending.size() > 4096) drain_events(ctx);
-  return RTX_OK;
+  return st;
 }
 
 rtx_status rtx_render(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_host) {
@@ -425,6 +731,7 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
   out->paths = c[0]; out->segments = c[1]; out->pdf_probes = c[2];
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
+  out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   return RTX_OK;
 }
 
@@ -434,7 +741,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)));
-  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0;
+  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0;
   return RTX_OK;
 }
 

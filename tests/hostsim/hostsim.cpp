@@ -7,22 +7,30 @@
 #include <thread>
 #include <vector>
 
+#include "../../raytracing_rust_amd/csrc/core/rt_program.h"
 #include "../../raytracing_rust_amd/csrc/core/rt_shade.h"
 
 using namespace rt;
 
 extern "C" {
 
-int sim_first_hit(const rtx_scene_desc* S, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
+int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                   uint32_t* mat_id, uint8_t* front) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene view = prog.host_view(*desc);
+  const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
     const double* r = rays + 7 * i;
     Ray ray;
     ray.o = v3(r[0], r[1], r[2]); ray.d = v3(r[3], r[4], r[5]); ray.tm = r[6];
     Hit h;
-    bool any = closest_hit<false>(*S, S->world_begin, S->world_end, ray, 0, 0.001, RT_INF, h, nullptr, 0);
+    RayRegs rs;
+    rs.r = ray;
+    closest_hit<false>(*S, S->prog, S->world_begin, true, rs, ray.tm, 0.001, RT_INF, h, false, PathRng(), 0, nullptr);
+    const bool any = hit_any(h);
     Surface sf;
-    if (any) resolve_hit(*S, ray, h, false, sf);
+    if (any) resolve_hit(*S, ray, h, false, nullptr, sf);
     if (t) t[i] = any ? h.t : RT_INF;
     if (normal) { normal[3 * i] = any ? sf.n.x : 0; normal[3 * i + 1] = any ? sf.n.y : 0; normal[3 * i + 2] = any ? sf.n.z : 0; }
     if (prim_id) prim_id[i] = any ? sf.prim_id : 0xFFFFFFFFu;
@@ -33,8 +41,12 @@ int sim_first_hit(const rtx_scene_desc* S, const double* rays, size_t n, double*
 }
 
 // counters: paths, segments, pdf_probes
-int sim_render(const rtx_scene_desc* S, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
+int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
                uint64_t* counters, int nthreads) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene view = prog.host_view(*desc);
+  const Scene* S = &view;
   if (nthreads < 1) nthreads = 1;
   const int W = cam->image_width;
   std::atomic<int> next_row(o->y0);
@@ -79,16 +91,28 @@ double sim_rng_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t s
 }
 void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 void sim_philox10(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32_r<10>(c[0], c[1], c[2], c[3], k[0], k[1], out); }
-void sim_texture_value(const rtx_scene_desc* S, uint32_t tex, const double* uvp, size_t n, double* out) {
+void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* uvp, size_t n, double* out) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene view = prog.host_view(*desc);
+  const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
     V3 c = texture_value(*S, tex, uvp[5 * i], uvp[5 * i + 1], v3(uvp + 5 * i + 2));
     out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
   }
 }
-void sim_lights_pdf(const rtx_scene_desc* S, const double* origin, const double* dirs, size_t n, double* out) {
+void sim_lights_pdf(const rtx_scene_desc* desc, const double* origin, const double* dirs, size_t n, double* out) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene view = prog.host_view(*desc);
+  const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); }
 }
-void sim_lights_random(const rtx_scene_desc* S, const double* origin, uint64_t seed, size_t n, double* out) {
+void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_t seed, size_t n, double* out) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene view = prog.host_view(*desc);
+  const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
     PathRng r = rng_make(seed, (uint32_t)i, 0);
     V3 d = lights_random(*S, v3(origin), r);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel trace + two PMC passes of a one-step bench; prints a summary.
+# usage: tools/prof_gpu.sh <tag> [bench args...]
+set -u
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag
+mkdir -p $out
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/trace.log 2>&1 || { echo trace failed; tail -5 $out/trace.log; exit 1; }
+cut -d, -f1-6 $out/trace/t_kernel_stats.csv | head -8
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmcA -o a -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcA.log 2>&1 || { echo pmcA failed; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --output-format csv -d $out/pmcB -o b -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcB.log 2>&1 || { echo pmcB failed; exit 1; }
+python3 tools/pmc_summary.py $out/pmcA $out/pmcB > $out/pmc_summary.txt
+head -40 $out/pmc_summary.txt
