@@ -23,12 +23,14 @@ struct CompiledProgram {
   std::vector<rtx_medium> media;   // copy of the scene's media with b_begin as a unit index (b_end is unused)
   std::vector<DSphere> dspheres;   // parallel to d.spheres
   std::vector<DAAQuad> daaquads;   // parallel to d.quads
+  std::vector<DBox6> dbox6;        // one per BOX6 unit
   std::vector<uint8_t> sphere_static, quad_aa;
   uint32_t world_begin = 0;
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program).
   void compile(const rtx_scene_desc& d) {
     units.clear();
+    dbox6.clear();
     build_compact(d);
     media.assign(d.media, d.media + d.n_media);
     world_begin = emit_range(d, d.world_begin, d.world_end, true);
@@ -48,7 +50,7 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S._pad1 = 0;
-    S.dspheres = dspheres.data(); S.daaquads = daaquads.data();
+    S.dspheres = dspheres.data(); S.daaquads = daaquads.data(); S.dbox6 = dbox6.data();
     return S;
   }
 
@@ -90,6 +92,26 @@ struct CompiledProgram {
     }
   }
 
+  static bool same_face(const DAAQuad& a, const DAAQuad& b) {
+    return a.axis == b.axis && a.d == b.d && a.nk == b.nk && a.qa == b.qa && a.qb == b.qb && a.ua == b.ua &&
+           a.ub == b.ub && a.va == b.va && a.vb == b.vb && a.wk == b.wk;
+  }
+  // Do quads[q0 .. q0+6) equal, field by field, the six faces box6_face() rebuilds from their corners?
+  bool try_box6(const rtx_scene_desc& d, uint32_t q0, DBox6& out) const {
+    if (q0 + 6 > d.n_quads) return false;
+    for (uint32_t k = 0; k < 6; ++k) if (!quad_aa[q0 + k]) return false;
+    const rtx_quad& front = d.quads[q0];       // q = (x0, y0, z1), u = (dx, 0, 0), v = (0, dy, 0)
+    const rtx_quad& back = d.quads[q0 + 2];    // q = (x1, y0, z0)
+    const rtx_quad& top = d.quads[q0 + 4];     // q = (x0, y1, z1)
+    out.x0 = front.q[0]; out.y0 = front.q[1]; out.z1 = front.q[2];
+    out.x1 = back.q[0]; out.z0 = back.q[2]; out.y1 = top.q[1];
+    out.wz = daaquads[q0].wk; out.wx = daaquads[q0 + 1].wk; out.wy = daaquads[q0 + 4].wk;
+    out.quad0 = q0; out._pad = 0;
+    for (int f = 0; f < 6; ++f)
+      if (!same_face(box6_face(out, f), daaquads[q0 + (uint32_t)f])) return false;
+    return true;
+  }
+
   // Appends nodes[b,e) + END; returns the unit index of the first record.  Consecutive static spheres / axis-aligned
   // quads whose table indices are consecutive too (the six faces of a box) become one run unit (count in the high
   // half); a run never spans a node some box skips to.  With `sync`, a SYNC unit follows every top-level box subtree
@@ -120,6 +142,30 @@ struct CompiledProgram {
       else
         items.push_back(Item{kind, idx, 1u, i});
     }
+    // split axis-aligned-quad runs: every six consecutive faces that form a box_new box become one BOX6 item
+    {
+      std::vector<Item> split;
+      for (const Item& it : items) {
+        if (it.kind != PROG_NODE_QUAD_AA) { split.push_back(it); continue; }
+        uint32_t k = 0;
+        while (k < it.count) {
+          DBox6 bx;
+          if (it.count - k >= 6 && try_box6(d, it.idx + k, bx)) {
+            split.push_back(Item{PROG_NODE_BOX6, (uint32_t)dbox6.size(), 6u, it.node + k});
+            dbox6.push_back(bx);
+            k += 6;
+          } else {
+            if (!split.empty() && split.back().kind == PROG_NODE_QUAD_AA && split.back().node + split.back().count == it.node + k &&
+                split.back().idx + split.back().count == it.idx + k && k > 0)
+              split.back().count += 1;
+            else
+              split.push_back(Item{PROG_NODE_QUAD_AA, it.idx + k, 1u, it.node + k});
+            k += 1;
+          }
+        }
+      }
+      items.swap(split);
+    }
     // unit positions; link[k] = where a skip to node b+k lands
     std::vector<uint32_t> link((size_t)n + 1, 0), item_pos(items.size());
     uint32_t at = (uint32_t)units.size();
@@ -145,7 +191,7 @@ struct CompiledProgram {
         units[p] = (uint64_t)nd.kind_idx | ((uint64_t)link[skip - b] << 32);
         units[p + 1] = 0;
         memcpy(&units[p + 2], &d.boxes[it.idx], sizeof(rtx_aabb));
-      } else if (it.kind == PROG_NODE_SPHERE_S || it.kind == PROG_NODE_QUAD_AA) {
+      } else if (it.kind == PROG_NODE_SPHERE_S || it.kind == PROG_NODE_QUAD_AA || it.kind == PROG_NODE_BOX6) {
         units[p] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
       } else {
         units[p] = (uint64_t)d.nodes[it.node].kind_idx;

@@ -26,12 +26,36 @@ struct DAAQuad {   // quad whose normal is exactly +-e_k (box faces, Cornell wal
   uint32_t axis, _pad;
 };
 
+// The six faces box_new builds (quad.rs:125-174) from two corners, as one record: the corners and the three
+// distinct w_k values (front, right, top; the opposite faces carry their negatives).  box6_face() rebuilds each
+// face's DAAQuad from it; the program compiler only emits a BOX6 unit after checking, field by field, that the six
+// rebuilt records equal the ones derived from the ABI quads, so a BOX6 test IS six aaquad_hit_t tests.
+struct DBox6 {
+  double x0, y0, z0, x1, y1, z1, wx, wy, wz;
+  uint32_t quad0, _pad;  // table index of the front face; the other five follow
+};
+RT_HD DAAQuad box6_face(const DBox6& r, int f) {
+  const double dx = r.x1 - r.x0, dy = r.y1 - r.y0, dz = r.z1 - r.z0;
+  DAAQuad q;
+  q._pad = 0;
+  switch (f) {
+    case 0: q.axis = 2; q.nk = 1.0;  q.d = r.z1;  q.qa = r.x0; q.qb = r.y0; q.ua = dx;  q.ub = 0.0; q.va = 0.0; q.vb = dy;  q.wk = r.wz;  break;  // front
+    case 1: q.axis = 0; q.nk = 1.0;  q.d = r.x1;  q.qa = r.y0; q.qb = r.z1; q.ua = 0.0; q.ub = -dz; q.va = dy;  q.vb = 0.0; q.wk = r.wx;  break;  // right
+    case 2: q.axis = 2; q.nk = -1.0; q.d = -r.z0; q.qa = r.x1; q.qb = r.y0; q.ua = -dx; q.ub = 0.0; q.va = 0.0; q.vb = dy;  q.wk = -r.wz; break;  // back
+    case 3: q.axis = 0; q.nk = -1.0; q.d = -r.x0; q.qa = r.y0; q.qb = r.z0; q.ua = 0.0; q.ub = dz;  q.va = dy;  q.vb = 0.0; q.wk = -r.wx; break;  // left
+    case 4: q.axis = 1; q.nk = 1.0;  q.d = r.y1;  q.qa = r.z1; q.qb = r.x0; q.ua = 0.0; q.ub = dx;  q.va = -dz; q.vb = 0.0; q.wk = r.wy;  break;  // top
+    default: q.axis = 1; q.nk = -1.0; q.d = -r.y0; q.qa = r.z0; q.qb = r.x0; q.ua = 0.0; q.ub = dx;  q.va = dz;  q.vb = 0.0; q.wk = -r.wy; break;  // bottom
+  }
+  return q;
+}
+
 // The scene as the kernels see it: the tables of rtx_scene_desc (device pointers on the GPU) plus the compiled hit
 // program (rt_program.h).  world_begin and media[].b_begin are UNIT indices into `prog` here.
 struct Scene : rtx_scene_desc {
   const uint64_t* prog;
   const DSphere* dspheres;   // parallel to spheres[]; valid where the program uses PROG_NODE_SPHERE_S
   const DAAQuad* daaquads;   // parallel to quads[]; valid where the program uses PROG_NODE_QUAD_AA
+  const DBox6* dbox6;        // records of the program's PROG_NODE_BOX6 units
   uint32_t n_units, _pad1;
 };
 #define PROG_BOX_UNITS 8u        // a BOX record: header unit, pad unit, six doubles
@@ -40,6 +64,12 @@ struct Scene : rtx_scene_desc {
 #define PROG_NODE_SPHERE_S 8u    // run of static spheres, compact records (hits are reported as RTX_NODE_SPHERE)
 #define PROG_NODE_QUAD_AA 9u     // run of axis-aligned quads, compact records (hits are reported as RTX_NODE_QUAD)
 #define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
+#define PROG_NODE_BOX6 11u       // the six axis-aligned faces of a box_new box (hits are reported as RTX_NODE_QUAD)
+
+// Test-only hook: a build may define RT_TRACE_STEP(kind) to record the unit kinds a ray steps through.
+#ifndef RT_TRACE_STEP
+#define RT_TRACE_STEP(kind) ((void)0)
+#endif
 
 // Wave-level votes.  On the GPU they steer the 64 lanes of a wave through the traversal loop together; in the host
 // build a "wave" is one ray and they reduce to the lane's own predicate.
@@ -113,27 +143,23 @@ RT_HD LRay lray_make(const Scene& S, uint32_t ctx, const V3& wo, const V3& wd) {
 // Aabb::hit, aabb.rs:132-167.  The per-axis early return is folded into one final comparison: the interval only
 // narrows, so it is empty at the end exactly when it was empty after some axis.
 RT_HD bool slab_hit(const double* b, const LRay& r, double tmin, double tmax) {  // b: lo[3], hi[3]
-  if ((r.skip & 7u) == 0) {
-    double t0 = (b[0] - r.o.x) * r.inv.x, t1 = (b[3] - r.o.x) * r.inv.x;
-    bool pos = r.inv.x >= 0.0;
-    tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    t0 = (b[1] - r.o.y) * r.inv.y; t1 = (b[4] - r.o.y) * r.inv.y;
-    pos = r.inv.y >= 0.0;
-    tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    t0 = (b[2] - r.o.z) * r.inv.z; t1 = (b[5] - r.o.z) * r.inv.z;
-    pos = r.inv.z >= 0.0;
-    tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    return !(tmax <= tmin);
+  // The reference computes both plane distances of an axis and then orders them by the sign of 1/d
+  // (aabb.rs:154-157).  Here the sign picks WHICH bound is read as the near one, so no value is selected after the
+  // arithmetic: near = (b[neg ? hi : lo] - o) * inv is the same operation on the same operands.
+  const uint32_t nx = r.inv.x >= 0.0 ? 0u : 3u, ny = r.inv.y >= 0.0 ? 0u : 3u, nz = r.inv.z >= 0.0 ? 0u : 3u;
+  const double bnx = b[nx], bfx = b[3u - nx], bny = b[1u + ny], bfy = b[4u - ny], bnz = b[2u + nz], bfz = b[5u - nz];
+  double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
+  double nry = (bny - r.o.y) * r.inv.y, fry = (bfy - r.o.y) * r.inv.y;
+  double nrz = (bnz - r.o.z) * r.inv.z, frz = (bfz - r.o.z) * r.inv.z;
+  if (r.skip & 7u) {  // a skipped axis (aabb.rs:142-144) leaves the interval untouched, like (-inf, +inf) does
+    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
+    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
+    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
   }
-  const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
-  for (int a = 0; a < 3; ++a) {
-    if (r.skip & (1u << a)) continue;
-    double t0 = (b[a] - o[a]) * inv[a], t1 = (b[3 + a] - o[a]) * inv[a];
-    bool pos = inv[a] >= 0.0;
-    tmin = fmax(tmin, pos ? t0 : t1); tmax = fmin(tmax, pos ? t1 : t0);
-    if (tmax <= tmin) return false;
-  }
-  return true;
+  tmin = fmax(tmin, nrx); tmax = fmin(tmax, frx);
+  tmin = fmax(tmin, nry); tmax = fmin(tmax, fry);
+  tmin = fmax(tmin, nrz); tmax = fmin(tmax, frz);
+  return !(tmax <= tmin);
 }
 
 // Sphere::hit up to the accepted root, sphere.rs:83-104.
@@ -281,7 +307,7 @@ template <bool MEDIA, class RaySrc>
 RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                        double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                        double* stale_uv) {
-  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6 };
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8 };
   uint32_t cur = 0;
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
@@ -296,18 +322,13 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
   bool running = active;
   uint64_t unit = running ? prog[i] : (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
   while (RT_WAVE_ANY(running)) {
-    // 1. boxes
-    while (RT_WAVE_ANY(running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX)) {
-      if (running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX) {
-        i = slab_hit((const double*)(prog + i + 2), lr, tmin, tmax) ? i + PROG_BOX_UNITS : (uint32_t)(unit >> 32);
-        unit = prog[i];
-      }
-    }
     const uint32_t kind_idx = (uint32_t)unit;
     const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
     int cls = CL_CHEAP;
-    if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    if (kind == RTX_NODE_BOX) cls = CL_BOX;
+    else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
     else if (kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
+    else if (kind == PROG_NODE_BOX6) cls = (lr.skip & 8u) ? CL_QUAD : CL_BOX6;
     else if (kind == RTX_NODE_SPHERE) cls = CL_SPHERE;
     else if (kind == RTX_NODE_QUAD) cls = CL_QUAD;
     else if (kind == PROG_NODE_SYNC) cls = CL_SYNC;
@@ -335,7 +356,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
           med = idx; ret_i = i + 1; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
           mode = 1; next = S.media[idx].b_begin; tmin = -RT_INF; tmax = RT_INF;
           hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
-        } else if (kind != RTX_NODE_BOX) {
+        } else {
           next = i + 1;  // NOP filler, or a medium the query ignores
         }
       }
@@ -343,9 +364,12 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
       // 3. every running lane stands on a primitive (or waits at a SYNC): run the class most lanes wait for
       const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
       const int n_s = RT_WAVE_COUNT(running && cls == CL_SPHERE), n_q = RT_WAVE_COUNT(running && cls == CL_QUAD);
-      const int n_m = RT_WAVE_COUNT(running && cls == CL_MEDIUM_EVAL);
+      const int n_m = RT_WAVE_COUNT(running && cls == CL_MEDIUM_EVAL), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
+      const int n_x = RT_WAVE_COUNT(running && cls == CL_BOX);
       int pick = CL_SYNC, best_n = 0;
+      if (n_x > best_n) { pick = CL_BOX; best_n = n_x; }
       if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
+      if (n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
       if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
       if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
       if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
@@ -353,11 +377,35 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
       if (pick == CL_SYNC) {
         // 4. everybody waits at a SYNC: pass it together
         if (running && cls == CL_SYNC) next = i + 1;
+      } else if (pick == CL_BOX) {
+        // boxes are the plurality: walk them until no lane stands on one (a tight loop: the vote costs more than a box)
+        do {
+          if (running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX) {
+            // both possible successors are read together with the bounds: one LDS round trip per box
+            const uint32_t i_pass = i + PROG_BOX_UNITS, i_fail = (uint32_t)(unit >> 32);
+            RT_TRACE_STEP(RTX_NODE_BOX);
+            const uint64_t u_pass = prog[i_pass], u_fail = prog[i_fail];
+            const bool pass = slab_hit((const double*)(prog + i + 2), lr, tmin, tmax);
+            i = pass ? i_pass : i_fail;
+            unit = pass ? u_pass : u_fail;
+          }
+        } while (RT_WAVE_ANY(running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX));
+        next = i;
       } else if (pick == CL_SPHERE_S) {
         if (running && cls == CL_SPHERE_S) {
           for (uint32_t k = 0; k < count; ++k) {
             double t;
             if (sphere_s_hit_t(S.dspheres[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1;
+        }
+      } else if (pick == CL_BOX6) {
+        if (running && cls == CL_BOX6) {
+          const DBox6 bx = S.dbox6[idx];
+RT_UNROLL
+          for (int f = 0; f < 6; ++f) {
+            double t;
+            if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, bx.quad0 + (uint32_t)f); hit_ctx = cur; }
           }
           next = i + 1;
         }
@@ -377,10 +425,12 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
         }
       } else if (pick == CL_QUAD) {
         if (running && cls == CL_QUAD) {  // a general quad, or a compact run met by a ray with non-finite components
-          const uint32_t cnt = kind == PROG_NODE_QUAD_AA ? count : 1u;
+          uint32_t first = idx, cnt = 1u;
+          if (kind == PROG_NODE_QUAD_AA) cnt = count;
+          else if (kind == PROG_NODE_BOX6) { first = S.dbox6[idx].quad0; cnt = 6u; }
           for (uint32_t k = 0; k < cnt; ++k) {
             double t;
-            if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+            if (quad_hit_t(S.quads[first + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, first + k); hit_ctx = cur; }
           }
           next = i + 1;
         }
@@ -412,7 +462,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
         }
       }
     }
-    if (running && next != i) { i = next; unit = prog[i]; }
+    if (running && next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
   }
   best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
 }

@@ -591,6 +591,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
   if (st == RTX_OK) st = upload(sc, prog.dspheres.data(), prog.dspheres.size(), &sc->dev.dspheres);
   if (st == RTX_OK) st = upload(sc, prog.daaquads.data(), prog.daaquads.size(), &sc->dev.daaquads);
+  if (st == RTX_OK) st = upload(sc, prog.dbox6.data(), prog.dbox6.size(), &sc->dev.dbox6);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
   UP(boxes, d->n_boxes); UP(spheres, d->n_spheres); UP(quads, d->n_quads);
   UP(xforms, d->n_xforms); UP(xform_ops, d->n_xform_ops); UP(materials, d->n_materials);

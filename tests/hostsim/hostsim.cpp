@@ -3,6 +3,11 @@
 // through the very code the HIP kernels run (hit-program traversal, shading,
 // RNG addressing) against the oracle without a GPU.  The product library does
 // not contain, link or load this file; it has no CPU path.
+#include <stdint.h>
+// step tracer for the scheduling study (tools/sched_sim.py): unit kinds a ray steps through, in order
+static thread_local uint8_t* g_trace = nullptr;
+static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
+#define RT_TRACE_STEP(kind) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = (uint8_t)(kind); } while (0)
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -76,6 +81,39 @@ int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx
     for (int t = 0; t < nthreads; ++t) { counters[0] += paths[(size_t)t]; counters[1] += segs[(size_t)t]; counters[2] += probes[(size_t)t]; }
   }
   return 0;
+}
+
+// For each ray: the kinds of the units it steps through (media included, RNG keyed by ray index).  seq is n x cap
+// bytes, len receives the per-ray lengths.
+void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, uint32_t cap, uint8_t* seq, uint32_t* len) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene S = prog.host_view(*desc);
+  for (size_t i = 0; i < n; ++i) {
+    const double* r = rays + 7 * i;
+    RayRegs rs;
+    rs.r.o = v3(r[0], r[1], r[2]); rs.r.d = v3(r[3], r[4], r[5]); rs.r.tm = r[6];
+    g_trace = seq + i * cap; g_trace_len = 0; g_trace_cap = cap;
+    Hit h;
+    PathRng rng = rng_make(12345, (uint32_t)i, 0);
+    double uv[2];
+    closest_hit<true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, h, true, rng, 0, uv);
+    len[i] = g_trace_len;
+    g_trace = nullptr;
+  }
+}
+
+// Histogram of unit kinds of the compiled program (16 counters) + total units in counts[16].
+void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  for (int k = 0; k < 17; ++k) counts[k] = 0;
+  for (size_t i = 0; i < prog.units.size();) {
+    const uint32_t kind = RTX_NODE_KIND((uint32_t)prog.units[i]);
+    counts[kind] += 1;
+    i += kind == RTX_NODE_BOX ? PROG_BOX_UNITS : 1;
+  }
+  counts[16] = (uint32_t)prog.units.size();
 }
 
 void sim_resolve_rgb8(const double* accum, int w, int h, int spp, uint8_t* rgb) {

@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Offline study of the traversal kernel's wave scheduling.
+
+Records, with the host build of the device core, the sequence of program units each ray of the final scene steps
+through, groups rays into waves of 64 and replays scheduling policies under a simple instruction-cost model.
+Prints VALU-instruction estimates per wave-segment for each policy.  Test/tuning tool, not part of the product.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import raytracing_rust_amd as rt  # noqa: E402
+from raytracing_rust_amd import _capi, scenes  # noqa: E402
+import helpers as H  # noqa: E402
+
+BOX, ENTER, EXIT, MEDIUM, NOP, END, SYNC = 0, 3, 4, 5, 6, 7, 10
+CL = {33: "SPHERE_S", 34: "QUAD_AA", 35: "SPHERE", 36: "QUAD", 37: "MEDEVAL", 38: "SYNC", 39: "BOX6"}
+COST = {BOX: 45, ENTER: 250, EXIT: 250, MEDIUM: 25, NOP: 10, END: 25, 33: 110, 34: 400, 35: 130, 36: 150, 37: 350, 38: 10, 39: 330}
+TRIP_OVERHEAD = 55
+
+
+def trace(desc, rays, cap=512):
+    lib = H.hostsim_lib()
+    lib.sim_trace_steps.argtypes = [C.POINTER(_capi.SceneDesc), H.PD, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]
+    n = len(rays)
+    seq = np.zeros((n, cap), dtype=np.uint8)
+    ln = np.zeros(n, dtype=np.uint32)
+    r = np.ascontiguousarray(rays)
+    lib.sim_trace_steps(C.byref(desc), H.dptr(r), n, cap, seq.ctypes.data_as(C.POINTER(C.c_uint8)), ln.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert ln.max() < cap
+    return [seq[i, :ln[i]] for i in range(n)]
+
+
+def simulate(wave, policy):
+    """wave: list of 64 sequences.  Returns (cost, trips per class)."""
+    ptr = [0] * len(wave)
+    cost = 0
+    trips = {}
+    while True:
+        cur = [w[p] if p < len(w) else None for w, p in zip(wave, ptr)]
+        live = [c for c in cur if c is not None]
+        if not live:
+            break
+        counts = {}
+        for c in live:
+            counts[c] = counts.get(c, 0) + 1
+        pick = policy(counts, len(live))
+        for k, c in enumerate(cur):
+            if c == pick:
+                ptr[k] += 1
+        cost += COST[pick] + TRIP_OVERHEAD
+        trips[pick] = trips.get(pick, 0) + 1
+    return cost, trips
+
+
+CHEAP = (BOX, ENTER, EXIT, MEDIUM, NOP, END)
+
+
+def pol_current(counts, nlive):
+    if BOX in counts:
+        return BOX
+    for c in (END, ENTER, EXIT, MEDIUM, NOP):
+        if c in counts:
+            return c
+    leaf = {c: n for c, n in counts.items() if c != 38}
+    if not leaf:
+        return 38
+    return max(leaf, key=lambda c: leaf[c])
+
+
+def pol_majority_weighted(counts, nlive):
+    """Everything competes; score = lanes / cost; SYNC only when alone."""
+    cand = {c: n for c, n in counts.items() if c != 38}
+    if not cand:
+        return 38
+    return max(cand, key=lambda c: cand[c] / (COST[c] + TRIP_OVERHEAD))
+
+
+def pol_majority_plain(counts, nlive):
+    cand = {c: n for c, n in counts.items() if c != 38}
+    if not cand:
+        return 38
+    return max(cand, key=lambda c: cand[c])
+
+
+def pol_box_threshold(th):
+    def pol(counts, nlive):
+        cand = {c: n for c, n in counts.items() if c != 38}
+        if not cand:
+            return 38
+        if counts.get(BOX, 0) >= th * nlive or set(cand) == {BOX}:
+            return BOX
+        nb = {c: n for c, n in cand.items() if c != BOX}
+        for c in (END, ENTER, EXIT, MEDIUM, NOP):
+            if c in nb:
+                return c
+        return max(nb, key=lambda c: nb[c]) if nb else BOX
+    return pol
+
+
+def report(name, seqs, group):
+    waves = [seqs[i:i + 64] for i in range(0, len(seqs) - 63, 64)] if group == "order" else None
+    if group == "random":
+        idx = np.random.default_rng(1).permutation(len(seqs))
+        waves = [[seqs[j] for j in idx[i:i + 64]] for i in range(0, len(seqs) - 63, 64)]
+    per_lane = np.mean([sum(COST[c] for c in s) for s in seqs])
+    mx = np.mean([max(sum(COST[c] for c in s) for s in w) for w in waves])
+    print(f"== {name} / {group}: {len(waves)} waves; converged ideal {per_lane:.0f}, mean of per-wave max lane {mx:.0f}, mean steps/lane {np.mean([len(s) for s in seqs]):.1f}")
+    pols = {"current": pol_current, "majority/cost": pol_majority_weighted, "majority": pol_majority_plain,
+            "box>=25%": pol_box_threshold(0.25), "box>=50%": pol_box_threshold(0.5)}
+    for pn, pol in pols.items():
+        res = [simulate(w, pol) for w in waves[:60]]
+        cost = np.mean([r[0] for r in res])
+        trips = {}
+        for r in res:
+            for c, n in r[1].items():
+                trips[c] = trips.get(c, 0) + n / len(res)
+        tr = " ".join(f"{CL.get(c, {0:'BOX',3:'ENT',4:'EXT',5:'MED',6:'NOP',7:'END'}.get(c, c))}:{n:.0f}" for c, n in sorted(trips.items()))
+        print(f"   {pn:14s} cost {cost:8.0f}   trips {tr}")
+
+
+def main():
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    # primary rays in 8x8 tiles
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    prim = trace(desc, tiles)
+    report("primary", prim, "order")
+    # secondary rays: cosine-ish directions about the first-hit normal
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    d[~ok] = rng.normal(size=(int((~ok).sum()), 3))
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    secs = trace(desc, sec)
+    report("secondary", secs, "order")
+    report("secondary", secs, "random")
+
+
+if __name__ == "__main__" and "--refill" not in sys.argv and "--sort" not in sys.argv:
+    main()
+
+
+def simulate_refill(seqs, policy, lanes=64, sync_as_nop=True):
+    """Persistent wave: a lane that finishes its ray takes the next one from the pool.  Returns cost per ray."""
+    pool = list(seqs)
+    nxt = 0
+    cur_seq = [None] * lanes
+    ptr = [0] * lanes
+    for k in range(lanes):
+        if nxt < len(pool):
+            cur_seq[k] = pool[nxt]; nxt += 1
+    cost = 0
+    trips = {}
+    while True:
+        cur = []
+        for k in range(lanes):
+            while cur_seq[k] is not None and ptr[k] >= len(cur_seq[k]):
+                if nxt < len(pool):
+                    cur_seq[k] = pool[nxt]; nxt += 1; ptr[k] = 0
+                else:
+                    cur_seq[k] = None
+            c = cur_seq[k][ptr[k]] if cur_seq[k] is not None else None
+            if sync_as_nop and c == 38:
+                c = NOP
+            cur.append(c)
+        live = [c for c in cur if c is not None]
+        if not live:
+            break
+        counts = {}
+        for c in live:
+            counts[c] = counts.get(c, 0) + 1
+        pick = policy(counts, len(live))
+        for k, c in enumerate(cur):
+            if c == pick:
+                ptr[k] += 1
+        cost += COST[pick] + TRIP_OVERHEAD
+        trips[pick] = trips.get(pick, 0) + 1
+    return cost / len(pool) * 64, {c: n / len(pool) * 64 for c, n in trips.items()}
+
+
+def report_refill(name, seqs):
+    print(f"== {name} / persistent wave with refill (cost per 64 rays)")
+    for pn, pol in {"current": pol_current, "majority/cost": pol_majority_weighted, "majority": pol_majority_plain}.items():
+        cost, trips = simulate_refill(seqs[:64 * 40], pol)
+        tr = " ".join(f"{CL.get(c, {0:'BOX',3:'ENT',4:'EXT',5:'MED',6:'NOP',7:'END'}.get(c, c))}:{n:.0f}" for c, n in sorted(trips.items()))
+        print(f"   {pn:14s} cost {cost:8.0f}   trips {tr}")
+
+
+if __name__ == "__main__" and "--refill" in sys.argv and "--sort" not in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    secs = trace(desc, sec)
+    report_refill("secondary", secs)
+
+
+def morton3(ix, iy, iz, bits=5):
+    code = np.zeros_like(ix)
+    for b in range(bits):
+        code |= ((ix >> b) & 1) << (3 * b) | ((iy >> b) & 1) << (3 * b + 1) | ((iz >> b) & 1) << (3 * b + 2)
+    return code
+
+
+if __name__ == "__main__" and "--sort" in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=192, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3)
+    hit = H.hostsim_first_hit(desc, rays)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = rays[:, 0:3] + rays[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(rays), 3)) * 0.8
+    sec = np.concatenate([p, d, rays[:, 6:7]], axis=1)[ok]
+    sec = sec[rng.permutation(len(sec))][:64 * 120]
+    secs = trace(desc, sec)
+    def run(order, name):
+        s2 = [secs[i] for i in order]
+        waves = [s2[i:i + 64] for i in range(0, len(s2) - 63, 64)]
+        cost = np.mean([simulate(wv, pol_majority_plain)[0] for wv in waves[:80]])
+        cost_r, _ = simulate_refill(s2[:64 * 60], pol_majority_plain)
+        print(f"   {name:34s} majority {cost:8.0f}   majority+refill {cost_r:8.0f}")
+    n = len(secs)
+    print("== secondary rays, wave grouping by sort key")
+    run(np.arange(n), "random")
+    o = sec[:, 0:3]; dd = sec[:, 3:6]
+    octant = (dd[:, 0] > 0).astype(np.int64) | ((dd[:, 1] > 0).astype(np.int64) << 1) | ((dd[:, 2] > 0).astype(np.int64) << 2)
+    cell = np.clip(((o + 1000.0) / 2000.0 * 32).astype(np.int64), 0, 31)
+    mort = morton3(cell[:, 0], cell[:, 1], cell[:, 2])
+    run(np.argsort(octant, kind="stable"), "direction octant")
+    run(np.argsort(mort, kind="stable"), "origin morton (32^3)")
+    run(np.argsort(octant * (1 << 15) + mort, kind="stable"), "octant, then origin morton")
+    run(np.argsort(mort * 8 + octant, kind="stable"), "origin morton, then octant")
+    ln = np.array([len(s) for s in secs])
+    run(np.argsort(ln, kind="stable"), "oracle: by sequence length")
