@@ -20,7 +20,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
-SEGMENT_BYTES = 328                          # algorithmic bytes per ray segment of a whole bounce
+# Algorithmic bytes per ray segment.  Traversal kernel (the dominant one): reads the ray (origin, direction, time:
+# 7 doubles) and, because the scene has media, the path's RNG address (pixel, sample, bounce: 3 u32); writes the hit
+# (t f64, kind_idx u32, ctx u32): 56 + 12 + 16 = 84 B.  A whole bounce adds the shading kernel's reads (ray 56 +
+# throughput 24 + ids 12 + hit 16 = 108 B) and its survivor record (80 + 12 = 92 B) or pixel atomics (24 B): ~300 B.
+TRAVERSE_BYTES = 84
+BOUNCE_BYTES = 300
 HBM_PEAK_GBS = 8000.0
 
 
@@ -46,7 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=8)
+    ap.add_argument("--cpu-samples", type=int, default=256)
     args = ap.parse_args()
 
     import torch
@@ -115,9 +120,13 @@ def main():
     if rank == 0:
         assert bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
         assert paths == npix * rows * args.steps * world_size
-        kernel_ms = st["render_ms"] / max(1, st["launches"])         # HIP events around each launch, rank 0's stream
-        seg_per_launch = st["segments"] / max(1, st["launches"])
-        achieved = seg_per_launch * SEGMENT_BYTES / (kernel_ms * 1e-3) / 1e9
+        # HIP events around every k_wf_traverse launch, recorded by the library on the stream it launches on (rank 0)
+        fused = st["traverse_launches"] == 0
+        n_launch = st["launches"] if fused else st["traverse_launches"]
+        kernel_ms = (st["render_ms"] if fused else st["traverse_ms"]) / max(1, n_launch)
+        seg_per_launch = st["segments"] / max(1, n_launch)
+        seg_bytes = BOUNCE_BYTES if fused else TRAVERSE_BYTES
+        achieved = seg_per_launch * seg_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Msamples/s (node) final scene 800x800", "value": paths / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -128,8 +137,12 @@ def main():
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_render_fused", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": seg_per_launch * SEGMENT_BYTES},
+                         "kernel": "k_render_fused" if fused else "k_wf_traverse", "kernel_ms": kernel_ms,
+                         "launches": n_launch, "segments_per_launch": seg_per_launch,
+                         "algorithmic_bytes_per_segment": seg_bytes,
+                         "algorithmic_bytes_per_launch": seg_per_launch * seg_bytes,
+                         "traverse_share_of_render_time": None if fused else st["traverse_ms"] / max(1e-9, st["render_ms"]),
+                         "note": "f64 VALU/latency-bound BVH walk out of LDS; HBM streams are the only bytes it must move"},
         }
         if world_size == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_amd.so")
+LIB_PATH = os.environ.get("RTX_AMD_LIB") or os.path.join(_HERE, "librtx_amd.so")  # RTX_AMD_LIB: a tuning build
 
 u32, u64, i32, f64, u8 = C.c_uint32, C.c_uint64, C.c_int32, C.c_double, C.c_uint8
 f64x3 = f64 * 3

@@ -1,12 +1,21 @@
-// Compilation of the boundary's hit program (rtx_scene_desc.nodes) into the layout the kernels walk.
+// Compilation of the boundary's hit program (rtx_scene_desc.nodes) into the image the kernels walk.
 //
-// The ABI keeps nodes and boxes in separate tables.  For the device the program becomes one array of 8-byte units
-// so that a box test needs a single address: a BOX record is 8 units (header, pad, lo[3], hi[3]; 64 B, 16-byte
-// aligned so that the six doubles can be read as three 16-byte loads from LDS), every other record is one unit.
-// Unit = kind_idx (low 32 bits, as RTX_NODE_MAKE) | skip << 32 (BOX: unit index to continue at on a miss).
-// NOP units keep BOX records on even unit positions; an END unit closes the world program and every medium boundary
-// program, so the walker needs no end index.  Static spheres and quads whose normal is an exact coordinate axis get
-// compact records (DSphere, DAAQuad) and their own unit kinds.  Visiting order and links are unchanged.
+// The ABI keeps nodes, boxes, primitives, transforms and media in separate tables.  For the device the program
+// becomes ONE array of 8-byte units in which every record carries the operands its step needs, so that a walk reads a
+// single address space (the whole image is staged in LDS when it fits) and never gathers from the tables:
+//
+//   unit = kind_idx (low 32 bits, as RTX_NODE_MAKE) | aux << 32, followed by the record's payload units
+//   BOX       aux = unit index to continue at on a miss        payload lo[3], hi[3]                       (7 units)
+//   SPHERE_S  idx = first sphere, aux = count                  payload count x {cx, cy, cz, r}
+//   QUAD_AA   idx = first quad, aux = count                    payload count x DAAQuad (10 units)
+//   BOX6      idx = first of the six quads                     payload DBox6 (9 doubles)
+//   ENTER/EXIT idx = transform context, aux = op count         payload ops x {kind, a, b, c}
+//   MEDIUM    idx = medium, aux = first unit of its boundary   payload {neg_inv_density, needs_uv}
+//   SPHERE, QUAD (moving spheres, general quads): no payload, the walker reads the ABI tables
+//   SYNC, NOP, END: no payload; an END closes the world program and every medium boundary program.
+//
+// Visiting order and skip links are those of the ABI program.  Static spheres and quads whose normal is an exact
+// coordinate axis get the compact records above; six consecutive faces that box_new built become one BOX6.
 #pragma once
 #include <math.h>
 #include <string.h>
@@ -21,25 +30,25 @@ namespace rt {
 struct CompiledProgram {
   std::vector<uint64_t> units;
   std::vector<rtx_medium> media;   // copy of the scene's media with b_begin as a unit index (b_end is unused)
-  std::vector<DSphere> dspheres;   // parallel to d.spheres
-  std::vector<DAAQuad> daaquads;   // parallel to d.quads
-  std::vector<DBox6> dbox6;        // one per BOX6 unit
+  std::vector<DAAQuad> daaquads;   // parallel to d.quads; valid where quad_aa[] is set
   std::vector<uint8_t> sphere_static, quad_aa;
   uint32_t world_begin = 0;
+  uint32_t n_box6 = 0;
 
-  // `d` must already be validated (index ranges, forward skip links that stay inside their program).
+  // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
+  // a medium boundary).
   void compile(const rtx_scene_desc& d) {
     units.clear();
-    dbox6.clear();
+    n_box6 = 0;
     build_compact(d);
     media.assign(d.media, d.media + d.n_media);
-    world_begin = emit_range(d, d.world_begin, d.world_end, true);
-    for (uint32_t m = 0; m < d.n_media; ++m) {
+    for (uint32_t m = 0; m < d.n_media; ++m) {  // boundaries first: MEDIUM units of the world point at them
       media[m].b_begin = emit_range(d, d.media[m].b_begin, d.media[m].b_end, false);
       media[m].b_end = 0;
     }
-    if (units.size() & 1u) units.push_back(nop());   // even unit count: the program is copied in 16-byte pieces
-    units.insert(units.end(), PROG_BOX_UNITS, nop()); // tail pad: reads of a whole record never leave the array
+    world_begin = emit_range(d, d.world_begin, d.world_end, true);
+    if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
+    units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
   }
 
   // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
@@ -50,22 +59,18 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S._pad1 = 0;
-    S.dspheres = dspheres.data(); S.daaquads = daaquads.data(); S.dbox6 = dbox6.data();
     return S;
   }
 
  private:
   static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }
+  static uint64_t bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 
   void build_compact(const rtx_scene_desc& d) {
-    dspheres.assign(d.n_spheres, DSphere{0, 0, 0, 0});
     sphere_static.assign(d.n_spheres, 0);
     for (uint32_t i = 0; i < d.n_spheres; ++i) {
       const rtx_sphere& s = d.spheres[i];
-      if (s.dc[0] == 0.0 && s.dc[1] == 0.0 && s.dc[2] == 0.0) {
-        sphere_static[i] = 1;
-        dspheres[i] = DSphere{s.c0[0], s.c0[1], s.c0[2], s.radius};
-      }
+      if (s.dc[0] == 0.0 && s.dc[1] == 0.0 && s.dc[2] == 0.0) sphere_static[i] = 1;
     }
     DAAQuad zero;
     memset(&zero, 0, sizeof(zero));
@@ -106,16 +111,29 @@ struct CompiledProgram {
     out.x0 = front.q[0]; out.y0 = front.q[1]; out.z1 = front.q[2];
     out.x1 = back.q[0]; out.z0 = back.q[2]; out.y1 = top.q[1];
     out.wz = daaquads[q0].wk; out.wx = daaquads[q0 + 1].wk; out.wy = daaquads[q0 + 4].wk;
-    out.quad0 = q0; out._pad = 0;
     for (int f = 0; f < 6; ++f)
       if (!same_face(box6_face(out, f), daaquads[q0 + (uint32_t)f])) return false;
     return true;
   }
 
+  struct Item { uint32_t kind, idx, count, node; DBox6 box6; };
+
+  static uint32_t item_units(const rtx_scene_desc& d, const Item& it) {
+    switch (it.kind) {
+      case RTX_NODE_BOX: return PROG_BOX_UNITS;
+      case PROG_NODE_SPHERE_S: return 1u + PROG_SPHERE_S_UNITS * it.count;
+      case PROG_NODE_QUAD_AA: return 1u + PROG_QUAD_AA_UNITS * it.count;
+      case PROG_NODE_BOX6: return PROG_BOX6_UNITS;
+      case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * d.xforms[it.idx].n_ops;
+      case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
+      default: return 1u;
+    }
+  }
+
   // Appends nodes[b,e) + END; returns the unit index of the first record.  Consecutive static spheres / axis-aligned
-  // quads whose table indices are consecutive too (the six faces of a box) become one run unit (count in the high
-  // half); a run never spans a node some box skips to.  With `sync`, a SYNC unit follows every top-level box subtree
-  // of the range (skip links that end such a subtree land on the SYNC).
+  // quads whose table indices are consecutive too (the six faces of a box) become one run unit; a run never spans a
+  // node some box skips to.  With `sync`, a SYNC unit follows every top-level box subtree of the range (skip links
+  // that end such a subtree land on the SYNC).
   uint32_t emit_range(const rtx_scene_desc& d, uint32_t b, uint32_t e, bool sync) {
     const uint32_t n = e - b;
     std::vector<uint8_t> target((size_t)n + 1, 0), sync_before((size_t)n + 1, 0);
@@ -127,7 +145,8 @@ struct CompiledProgram {
       if (sync && i >= enclosing_end) sync_before[skip - b] = 1;
       enclosing_end = std::max(enclosing_end, skip);
     }
-    struct Item { uint32_t kind, idx, count, node; };
+    DBox6 no_box;
+    memset(&no_box, 0, sizeof(no_box));
     std::vector<Item> items;
     for (uint32_t i = b; i < e; ++i) {
       uint32_t kind = RTX_NODE_KIND(d.nodes[i].kind_idx);
@@ -140,7 +159,7 @@ struct CompiledProgram {
           items.back().count < 64)
         items.back().count += 1;
       else
-        items.push_back(Item{kind, idx, 1u, i});
+        items.push_back(Item{kind, idx, 1u, i, no_box});
     }
     // split axis-aligned-quad runs: every six consecutive faces that form a box_new box become one BOX6 item
     {
@@ -151,15 +170,15 @@ struct CompiledProgram {
         while (k < it.count) {
           DBox6 bx;
           if (it.count - k >= 6 && try_box6(d, it.idx + k, bx)) {
-            split.push_back(Item{PROG_NODE_BOX6, (uint32_t)dbox6.size(), 6u, it.node + k});
-            dbox6.push_back(bx);
+            split.push_back(Item{PROG_NODE_BOX6, it.idx + k, 6u, it.node + k, bx});
+            n_box6 += 1;
             k += 6;
           } else {
             if (!split.empty() && split.back().kind == PROG_NODE_QUAD_AA && split.back().node + split.back().count == it.node + k &&
                 split.back().idx + split.back().count == it.idx + k && k > 0)
               split.back().count += 1;
             else
-              split.push_back(Item{PROG_NODE_QUAD_AA, it.idx + k, 1u, it.node + k});
+              split.push_back(Item{PROG_NODE_QUAD_AA, it.idx + k, 1u, it.node + k, no_box});
             k += 1;
           }
         }
@@ -171,30 +190,52 @@ struct CompiledProgram {
     uint32_t at = (uint32_t)units.size();
     for (size_t k = 0; k < items.size(); ++k) {
       const uint32_t rel = items[k].node - b;
-      const bool box = items[k].kind == RTX_NODE_BOX;
       if (sync_before[rel]) { link[rel] = at; at += 1; }
-      if (box && (at & 1u)) ++at;  // NOP filler keeps BOX records 16-byte aligned
       item_pos[k] = at;
       if (!sync_before[rel]) link[rel] = at;
-      at += box ? PROG_BOX_UNITS : 1u;
+      at += item_units(d, items[k]);
     }
-    if (sync_before[n]) { link[n] = at; at += 1; } else { link[n] = at; }
+    link[n] = at;
+    if (sync_before[n]) at += 1;
     const uint32_t end_at = at;
     units.resize((size_t)end_at + 1, nop());
     for (size_t k = 0; k < items.size(); ++k) {
       const Item& it = items[k];
       const uint32_t p = item_pos[k], rel = it.node - b;
       if (sync_before[rel]) units[link[rel]] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_SYNC, 0);
+      uint64_t* u = &units[p];
       if (it.kind == RTX_NODE_BOX) {
         const rtx_node nd = d.nodes[it.node];
         const uint32_t skip = std::min(std::max(nd.skip, b), e);
-        units[p] = (uint64_t)nd.kind_idx | ((uint64_t)link[skip - b] << 32);
-        units[p + 1] = 0;
-        memcpy(&units[p + 2], &d.boxes[it.idx], sizeof(rtx_aabb));
-      } else if (it.kind == PROG_NODE_SPHERE_S || it.kind == PROG_NODE_QUAD_AA || it.kind == PROG_NODE_BOX6) {
-        units[p] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
+        u[0] = (uint64_t)nd.kind_idx | ((uint64_t)link[skip - b] << 32);
+        memcpy(u + 1, &d.boxes[it.idx], sizeof(rtx_aabb));
+      } else if (it.kind == PROG_NODE_SPHERE_S) {
+        u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
+        for (uint32_t s = 0; s < it.count; ++s) {
+          const rtx_sphere& sp = d.spheres[it.idx + s];
+          const DSphere rec = {sp.c0[0], sp.c0[1], sp.c0[2], sp.radius};
+          memcpy(u + 1 + PROG_SPHERE_S_UNITS * s, &rec, sizeof(rec));
+        }
+      } else if (it.kind == PROG_NODE_QUAD_AA) {
+        u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
+        for (uint32_t s = 0; s < it.count; ++s) memcpy(u + 1 + PROG_QUAD_AA_UNITS * s, &daaquads[it.idx + s], sizeof(DAAQuad));
+      } else if (it.kind == PROG_NODE_BOX6) {
+        u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)6u << 32);
+        memcpy(u + 1, &it.box6, sizeof(DBox6));
+      } else if (it.kind == RTX_NODE_ENTER || it.kind == RTX_NODE_EXIT) {
+        const rtx_xform x = d.xforms[it.idx];
+        u[0] = (uint64_t)d.nodes[it.node].kind_idx | ((uint64_t)x.n_ops << 32);
+        for (uint32_t s = 0; s < x.n_ops; ++s) {
+          const rtx_xform_op op = d.xform_ops[x.first_op + s];
+          uint64_t* r = u + 1 + PROG_XFORM_OP_UNITS * s;
+          r[0] = (uint64_t)op.kind; r[1] = bits(op.a); r[2] = bits(op.b); r[3] = bits(op.c);
+        }
+      } else if (it.kind == RTX_NODE_MEDIUM) {
+        u[0] = (uint64_t)d.nodes[it.node].kind_idx | ((uint64_t)media[it.idx].b_begin << 32);
+        u[1] = bits(d.media[it.idx].neg_inv_density);
+        u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
       } else {
-        units[p] = (uint64_t)d.nodes[it.node].kind_idx;
+        u[0] = (uint64_t)d.nodes[it.node].kind_idx;
       }
     }
     if (sync_before[n]) units[link[n]] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_SYNC, 0);

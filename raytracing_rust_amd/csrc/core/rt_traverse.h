@@ -32,7 +32,6 @@ struct DAAQuad {   // quad whose normal is exactly +-e_k (box faces, Cornell wal
 // rebuilt records equal the ones derived from the ABI quads, so a BOX6 test IS six aaquad_hit_t tests.
 struct DBox6 {
   double x0, y0, z0, x1, y1, z1, wx, wy, wz;
-  uint32_t quad0, _pad;  // table index of the front face; the other five follow
 };
 RT_HD DAAQuad box6_face(const DBox6& r, int f) {
   const double dx = r.x1 - r.x0, dy = r.y1 - r.y0, dz = r.z1 - r.z0;
@@ -53,18 +52,35 @@ RT_HD DAAQuad box6_face(const DBox6& r, int f) {
 // program (rt_program.h).  world_begin and media[].b_begin are UNIT indices into `prog` here.
 struct Scene : rtx_scene_desc {
   const uint64_t* prog;
-  const DSphere* dspheres;   // parallel to spheres[]; valid where the program uses PROG_NODE_SPHERE_S
-  const DAAQuad* daaquads;   // parallel to quads[]; valid where the program uses PROG_NODE_QUAD_AA
-  const DBox6* dbox6;        // records of the program's PROG_NODE_BOX6 units
   uint32_t n_units, _pad1;
 };
-#define PROG_BOX_UNITS 8u        // a BOX record: header unit, pad unit, six doubles
-#define PROG_NODE_NOP 6u         // alignment filler
+// record sizes in units (header included)
+#define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
+#define PROG_SPHERE_S_UNITS 4u   // per sphere of a run (DSphere)
+#define PROG_QUAD_AA_UNITS 10u   // per quad of a run (DAAQuad)
+#define PROG_BOX6_UNITS 10u      // header + DBox6
+#define PROG_XFORM_OP_UNITS 4u   // per transform op of an ENTER/EXIT record: kind, a, b, c
+#define PROG_MEDIUM_UNITS 3u     // header, neg_inv_density, needs_uv
+#define PROG_NODE_NOP 6u         // filler
 #define PROG_NODE_END 7u         // end of a program (the world's, or a medium boundary's)
 #define PROG_NODE_SPHERE_S 8u    // run of static spheres, compact records (hits are reported as RTX_NODE_SPHERE)
 #define PROG_NODE_QUAD_AA 9u     // run of axis-aligned quads, compact records (hits are reported as RTX_NODE_QUAD)
 #define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
 #define PROG_NODE_BOX6 11u       // the six axis-aligned faces of a box_new box (hits are reported as RTX_NODE_QUAD)
+
+// Units a record occupies, from its header unit.
+RT_HD uint32_t prog_record_units(uint64_t unit) {
+  const uint32_t kind = RTX_NODE_KIND((uint32_t)unit), aux = (uint32_t)(unit >> 32);
+  switch (kind) {
+    case RTX_NODE_BOX: return PROG_BOX_UNITS;
+    case PROG_NODE_SPHERE_S: return 1u + PROG_SPHERE_S_UNITS * aux;
+    case PROG_NODE_QUAD_AA: return 1u + PROG_QUAD_AA_UNITS * aux;
+    case PROG_NODE_BOX6: return PROG_BOX6_UNITS;
+    case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * aux;
+    case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
+    default: return 1u;
+  }
+}
 
 // Test-only hook: a build may define RT_TRACE_STEP(kind) to record the unit kinds a ray steps through.
 #ifndef RT_TRACE_STEP
@@ -73,6 +89,12 @@ struct Scene : rtx_scene_desc {
 
 // Wave-level votes.  On the GPU they steer the 64 lanes of a wave through the traversal loop together; in the host
 // build a "wave" is one ray and they reduce to the lane's own predicate.
+// Optional cycle accounting of the traversal loop (a tuning build defines RT_PROF_TRIP; the product does not).
+#ifndef RT_PROF_TRIP
+#define RT_PROF_START() do { } while (0)
+#define RT_PROF_LANES(n) do { } while (0)
+#define RT_PROF_TRIP(slot) do { } while (0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WAVE_ANY(p) (__ballot(p) != 0ull)
 #define RT_WAVE_COUNT(p) ((int)__popcll(__ballot(p)))
@@ -129,10 +151,32 @@ RT_HD V3 ctx_dir_to_world(const Scene& S, uint32_t ctx, V3 d) {
   return d;
 }
 
-RT_HD LRay lray_make(const Scene& S, uint32_t ctx, const V3& wo, const V3& wd) {
+// max/min of two doubles where a NaN operand loses (what `if x > m { m = x }` does, aabb.rs:154-164).  On the device
+// this is the bare v_max_f64 / v_min_f64: fmax()/fmin() would first re-quiet both operands (two more instructions
+// per call), which matters only for signalling NaNs, and no arithmetic result is one.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rt_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double rt_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+inline double rt_max(double a, double b) { return fmax(a, b); }
+inline double rt_min(double a, double b) { return fmin(a, b); }
+#endif
+
+// The local ray of a transform context from the op chain an ENTER/EXIT record carries (same operations as
+// ctx_to_local, operands read from the program image instead of the tables).
+RT_HD LRay lray_from_ops(const uint64_t* ops, uint32_t n_ops, const V3& wo, const V3& wd) {
   LRay l;
   l.o = wo; l.d = wd;
-  if (ctx != 0) ctx_to_local(S, ctx, l.o, l.d);
+  for (uint32_t k = 0; k < n_ops; ++k) {
+    const uint64_t* r = ops + PROG_XFORM_OP_UNITS * k;
+    const double* f = (const double*)r;
+    if ((uint32_t)r[0] == RTX_XF_TRANSLATE) {
+      l.o = l.o - v3(f[1], f[2], f[3]);
+    } else {
+      l.o = rot_w2l(l.o, f[1], f[2]);
+      l.d = rot_w2l(l.d, f[1], f[2]);
+    }
+  }
   l.inv = v3(1.0 / l.d.x, 1.0 / l.d.y, 1.0 / l.d.z);
   l.skip = (fabs(l.d.x) < 1e-8 ? 1u : 0u) | (fabs(l.d.y) < 1e-8 ? 2u : 0u) | (fabs(l.d.z) < 1e-8 ? 4u : 0u);
   const double mag = ((fabs(l.o.x) + fabs(l.o.y)) + fabs(l.o.z)) + ((fabs(l.d.x) + fabs(l.d.y)) + fabs(l.d.z));
@@ -156,9 +200,9 @@ RT_HD bool slab_hit(const double* b, const LRay& r, double tmin, double tmax) { 
     if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
     if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
   }
-  tmin = fmax(tmin, nrx); tmax = fmin(tmax, frx);
-  tmin = fmax(tmin, nry); tmax = fmin(tmax, fry);
-  tmin = fmax(tmin, nrz); tmax = fmin(tmax, frz);
+  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
+  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
+  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
   return !(tmax <= tmin);
 }
 
@@ -311,16 +355,17 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
   uint32_t cur = 0;
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
-  if (active) lr = lray_make(S, 0, rs.origin(), rs.dir());
+  if (active) lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
   uint32_t i = begin;
   double tmin = tmin0, tmax = tmax0;
   uint32_t hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0;
   // state of the enclosing query while a medium boundary program runs
   int mode = 0;  // 0: world program, 1: boundary entry query, 2: boundary exit query
-  uint32_t ret_i = 0, ret_cur = 0, out_kind = 0, out_ctx = 0, med = 0;
+  uint32_t ret_i = 0, ret_cur = 0, out_kind = 0, out_ctx = 0, med = 0, med_at = 0;
   double out_tmax = 0.0, t_entry = 0.0;
   bool running = active;
   uint64_t unit = running ? prog[i] : (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  RT_PROF_START();
   while (RT_WAVE_ANY(running)) {
     const uint32_t kind_idx = (uint32_t)unit;
     const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
@@ -335,6 +380,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
     else if (MEDIA && kind == PROG_NODE_END && mode == 2 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) cls = CL_MEDIUM_EVAL;
     uint32_t next = i;  // unit to stand on after this trip
     if (RT_WAVE_ANY(running && cls == CL_CHEAP)) {
+      RT_PROF_LANES(RT_WAVE_COUNT(running && cls == CL_CHEAP));
       // 2. other cheap units
       if (running && cls == CL_CHEAP) {
         if (kind == PROG_NODE_END) {
@@ -342,24 +388,25 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
             running = false;
           } else if (mode == 1 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) {  // entry found at tmax: look for the exit
             t_entry = tmax;
-            mode = 2; next = S.media[med].b_begin; tmin = t_entry + 0.0001; tmax = RT_INF;
+            mode = 2; next = (uint32_t)(prog[med_at] >> 32); tmin = t_entry + 0.0001; tmax = RT_INF;
             hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
           } else {                                                             // boundary missed: resume the world
             mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
           }
         } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
           cur = idx;
-          lr = lray_make(S, cur, rs.origin(), rs.dir());
-          next = i + 1;
+          lr = lray_from_ops(prog + i + 1, count, rs.origin(), rs.dir());
+          next = i + 1 + PROG_XFORM_OP_UNITS * count;
         } else if (MEDIA && kind == RTX_NODE_MEDIUM && use_media) {
           // save the enclosing query, run the boundary program from this context over the whole line
-          med = idx; ret_i = i + 1; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
-          mode = 1; next = S.media[idx].b_begin; tmin = -RT_INF; tmax = RT_INF;
+          med = idx; med_at = i; ret_i = i + PROG_MEDIUM_UNITS; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
+          mode = 1; next = count; tmin = -RT_INF; tmax = RT_INF;
           hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
         } else {
-          next = i + 1;  // NOP filler, or a medium the query ignores
+          next = i + (kind == RTX_NODE_MEDIUM ? PROG_MEDIUM_UNITS : 1u);  // a medium the query ignores, or filler
         }
       }
+      RT_PROF_TRIP(CL_CHEAP);
     } else {
       // 3. every running lane stands on a primitive (or waits at a SYNC): run the class most lanes wait for
       const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
@@ -367,55 +414,62 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
       const int n_m = RT_WAVE_COUNT(running && cls == CL_MEDIUM_EVAL), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
       const int n_x = RT_WAVE_COUNT(running && cls == CL_BOX);
       int pick = CL_SYNC, best_n = 0;
-      if (n_x > best_n) { pick = CL_BOX; best_n = n_x; }
       if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
       if (n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
       if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
       if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
       if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
       if (n_m > best_n) { pick = CL_MEDIUM_EVAL; best_n = n_m; }
+      // Boxes wait until no lane stands on a primitive, then every lane walks its boxes together: two alternating
+      // phases, so that a box trip serves as many lanes as possible.
+      if (best_n == 0 && n_x > 0) pick = CL_BOX;
+      RT_PROF_LANES(pick == CL_BOX ? 0 : best_n);
       if (pick == CL_SYNC) {
         // 4. everybody waits at a SYNC: pass it together
         if (running && cls == CL_SYNC) next = i + 1;
       } else if (pick == CL_BOX) {
-        // boxes are the plurality: walk them until no lane stands on one (a tight loop: the vote costs more than a box)
+        // walk boxes until no lane stands on one (a tight loop: a vote per step would cost more than the box test)
         do {
+          RT_PROF_LANES(RT_WAVE_COUNT(running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX));
           if (running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX) {
             // both possible successors are read together with the bounds: one LDS round trip per box
             const uint32_t i_pass = i + PROG_BOX_UNITS, i_fail = (uint32_t)(unit >> 32);
             RT_TRACE_STEP(RTX_NODE_BOX);
             const uint64_t u_pass = prog[i_pass], u_fail = prog[i_fail];
-            const bool pass = slab_hit((const double*)(prog + i + 2), lr, tmin, tmax);
+            const bool pass = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax);
             i = pass ? i_pass : i_fail;
             unit = pass ? u_pass : u_fail;
           }
+          RT_PROF_TRIP(9);
         } while (RT_WAVE_ANY(running && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX));
         next = i;
       } else if (pick == CL_SPHERE_S) {
         if (running && cls == CL_SPHERE_S) {
           for (uint32_t k = 0; k < count; ++k) {
             double t;
-            if (sphere_s_hit_t(S.dspheres[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
+            const DSphere sp = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
+            if (sphere_s_hit_t(sp, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
           }
-          next = i + 1;
+          next = i + 1 + PROG_SPHERE_S_UNITS * count;
         }
       } else if (pick == CL_BOX6) {
         if (running && cls == CL_BOX6) {
-          const DBox6 bx = S.dbox6[idx];
+          const DBox6 bx = *(const DBox6*)(prog + i + 1);
 RT_UNROLL
           for (int f = 0; f < 6; ++f) {
             double t;
-            if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, bx.quad0 + (uint32_t)f); hit_ctx = cur; }
+            if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; }
           }
-          next = i + 1;
+          next = i + PROG_BOX6_UNITS;
         }
       } else if (pick == CL_QUAD_AA) {
         if (running && cls == CL_QUAD_AA) {
           for (uint32_t k = 0; k < count; ++k) {
             double t;
-            if (aaquad_hit_t(S.daaquads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+            const DAAQuad qa = *(const DAAQuad*)(prog + i + 1 + PROG_QUAD_AA_UNITS * k);
+            if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
           }
-          next = i + 1;
+          next = i + 1 + PROG_QUAD_AA_UNITS * count;
         }
       } else if (pick == CL_SPHERE) {
         if (running && cls == CL_SPHERE) {
@@ -425,18 +479,19 @@ RT_UNROLL
         }
       } else if (pick == CL_QUAD) {
         if (running && cls == CL_QUAD) {  // a general quad, or a compact run met by a ray with non-finite components
-          uint32_t first = idx, cnt = 1u;
-          if (kind == PROG_NODE_QUAD_AA) cnt = count;
-          else if (kind == PROG_NODE_BOX6) { first = S.dbox6[idx].quad0; cnt = 6u; }
+          uint32_t cnt = 1u, size = 1u;
+          if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
+          else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
           for (uint32_t k = 0; k < cnt; ++k) {
             double t;
-            if (quad_hit_t(S.quads[first + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, first + k); hit_ctx = cur; }
+            if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
           }
-          next = i + 1;
+          next = i + size;
         }
       } else if (MEDIA) {
         if (running && cls == CL_MEDIUM_EVAL) {      // constant_medium.rs:60-87, exit found at tmax
-          const rtx_medium m = S.media[med];
+          const double neg_inv_density = ((const double*)prog)[med_at + 1];
+          const bool needs_uv = prog[med_at + 2] != 0;
           double t1 = fmax(t_entry, tmin0);
           double t2 = fmin(tmax, out_tmax);
           if (!(t1 >= t2)) {
@@ -444,9 +499,9 @@ RT_UNROLL
             double ray_length = norm(lr.d);
             double inside = (t2 - t1) * ray_length;
             double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
-            double hit_distance = m.neg_inv_density * log(xi);
+            double hit_distance = neg_inv_density * log(xi);
             if (!(hit_distance > inside)) {
-              if (m.needs_uv && stale_uv) {
+              if (needs_uv && stale_uv) {
                 stale_uv[0] = 0.0; stale_uv[1] = 0.0;
                 if (RTX_NODE_KIND(out_kind) == RTX_NODE_SPHERE || RTX_NODE_KIND(out_kind) == RTX_NODE_QUAD) {
                   Ray w;
@@ -461,6 +516,7 @@ RT_UNROLL
           mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
         }
       }
+      RT_PROF_TRIP(pick);
     }
     if (running && next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
   }

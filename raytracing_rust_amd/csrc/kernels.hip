@@ -11,6 +11,28 @@
 #include <vector>
 
 #include "../../include/rtx.h"
+
+#if defined(RT_PROF)
+// Tuning build only (make prof): cycles, trips and lanes per class of the traversal loop.  Wave leaders accumulate
+// in LDS; the traversal kernel flushes the block's sums to g_prof once, when it ends.
+__device__ unsigned long long g_prof[64];
+__shared__ unsigned long long g_prof_lds[16 * 30];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_PROF_START() long long prof_t0 = clock64(); int prof_lanes = 0; (void)prof_lanes
+#define RT_PROF_LANES(n) prof_lanes = (n)
+#define RT_PROF_TRIP(slot)                                                       \
+  do {                                                                           \
+    const long long t1_ = clock64();                                             \
+    if ((threadIdx.x & 63u) == 0) {                                              \
+      unsigned long long* p_ = g_prof_lds + (threadIdx.x >> 6) * 30;             \
+      p_[(slot)] += (unsigned long long)(t1_ - prof_t0);                         \
+      p_[10 + (slot)] += 1ull;                                                   \
+      p_[20 + (slot)] += (unsigned long long)prof_lanes;                         \
+    }                                                                            \
+    prof_t0 = clock64();                                                         \
+  } while (0)
+#endif
+#endif
 #include "core/rt_program.h"
 #include "core/rt_shade.h"
 
@@ -110,6 +132,10 @@ __global__ __launch_bounds__(1024) void k_wf_traverse(Scene S, uint32_t cap, uns
   const uint32_t n = c->n_in;
   if (blockIdx.x * blockDim.x >= n) return;
   const uint64_t* prog = S.prog;
+#if defined(RT_PROF)
+  for (uint32_t k = threadIdx.x; k < 16 * 30; k += blockDim.x) g_prof_lds[k] = 0;
+  __syncthreads();
+#endif
   if (USE_LDS) {
     const uint4* src = (const uint4*)S.prog;
     uint4* dst = (uint4*)lds_prog;
@@ -138,6 +164,14 @@ __global__ __launch_bounds__(1024) void k_wf_traverse(Scene S, uint32_t cap, uns
                       h.uv + 2 * (size_t)ld);
     if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
   }
+#if defined(RT_PROF)
+  __syncthreads();
+  if (threadIdx.x < 30) {
+    unsigned long long sum = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; ++w) sum += g_prof_lds[w * 30 + threadIdx.x];
+    atomicAdd(&g_prof[(threadIdx.x / 10) * 16 + threadIdx.x % 10], sum);
+  }
+#endif
 }
 
 // Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
@@ -460,7 +494,11 @@ static const char* validate_render(const rtx_camera_desc* cam, const rtx_render_
   return nullptr;
 }
 
+#if defined(RT_PROF)
+static const size_t kLdsBudget = 160 * 1024 - 4096;  // the tuning build keeps 4 KiB for its counters
+#else
 static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, one persistent workgroup per CU
+#endif
 
 static rtx_status wf_ensure(rtx_context* ctx) {
   if (ctx->wf_cap) return RTX_OK;
@@ -589,9 +627,6 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev._pad1 = 0;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
-  if (st == RTX_OK) st = upload(sc, prog.dspheres.data(), prog.dspheres.size(), &sc->dev.dspheres);
-  if (st == RTX_OK) st = upload(sc, prog.daaquads.data(), prog.daaquads.size(), &sc->dev.daaquads);
-  if (st == RTX_OK) st = upload(sc, prog.dbox6.data(), prog.dbox6.size(), &sc->dev.dbox6);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
   UP(boxes, d->n_boxes); UP(spheres, d->n_spheres); UP(quads, d->n_quads);
   UP(xforms, d->n_xforms); UP(xform_ops, d->n_xform_ops); UP(materials, d->n_materials);
@@ -747,3 +782,14 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
 }
 
 }  // extern "C"
+
+#if defined(RT_PROF)
+extern "C" int rtx_debug_prof_read(unsigned long long* out64, int reset) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long zero[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -111,7 +111,7 @@ void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   for (size_t i = 0; i < prog.units.size();) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)prog.units[i]);
     counts[kind] += 1;
-    i += kind == RTX_NODE_BOX ? PROG_BOX_UNITS : 1;
+    i += prog_record_units(prog.units[i]);
   }
   counts[16] = (uint32_t)prog.units.size();
 }

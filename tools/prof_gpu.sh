@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): kernel trace + two PMC passes of a one-step bench; prints a summary.
+# Run on the GPU box (through gpurun): kernel trace + four PMC passes (two SQ, FETCH_SIZE, WRITE_SIZE; each its own run) of a one-step bench; prints a summary.
 # usage: tools/prof_gpu.sh <tag> [bench args...]
 set -u
 tag=$1; shift
@@ -10,5 +10,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t
 cut -d, -f1-6 $out/trace/t_kernel_stats.csv | head -8
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmcA -o a -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcA.log 2>&1 || { echo pmcA failed; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR --output-format csv -d $out/pmcB -o b -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcB.log 2>&1 || { echo pmcB failed; exit 1; }
-python3 tools/pmc_summary.py $out/pmcA $out/pmcB > $out/pmc_summary.txt
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmcC -o c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcC.log 2>&1 || { echo pmcC failed; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmcD -o d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmcD.log 2>&1 || { echo pmcD failed; exit 1; }
+python3 tools/pmc_summary.py $out/pmcA $out/pmcB $out/pmcC $out/pmcD > $out/pmc_summary.txt
+cp $out/trace/t_kernel_stats.csv $out/kernel_stats.csv
 head -40 $out/pmc_summary.txt

@@ -145,7 +145,7 @@ def main():
     report("secondary", secs, "random")
 
 
-if __name__ == "__main__" and "--refill" not in sys.argv and "--sort" not in sys.argv:
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--refill", "--sort", "--phased")):
     main()
 
 
@@ -250,3 +250,56 @@ if __name__ == "__main__" and "--sort" in sys.argv:
     run(np.argsort(mort * 8 + octant, kind="stable"), "origin morton, then octant")
     ln = np.array([len(s) for s in secs])
     run(np.argsort(ln, kind="stable"), "oracle: by sequence length")
+
+
+class PolPhased:
+    """Two alternating phases: walk boxes until no lane stands on one, then drain every non-box unit until no lane
+    stands on one (largest class first), and so on.  SYNC is passed only when nothing else is left."""
+    def __init__(self):
+        self.phase = "box"
+
+    def __call__(self, counts, nlive):
+        cand = {c: n for c, n in counts.items() if c != 38}
+        if not cand:
+            return 38
+        if self.phase == "box":
+            if BOX in cand:
+                return BOX
+            self.phase = "leaf"
+        nb = {c: n for c, n in cand.items() if c != BOX}
+        if not nb:
+            self.phase = "box"
+            return BOX
+        for c in (END, ENTER, EXIT, MEDIUM, NOP):
+            if c in nb:
+                return c
+        return max(nb, key=lambda c: nb[c])
+
+
+if __name__ == "__main__" and "--phased" in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    secs = trace(desc, sec)
+    waves = [secs[i:i + 64] for i in range(0, len(secs) - 63, 64)]
+    for pn, mk in {"current": lambda: pol_current, "phased": PolPhased}.items():
+        res = [simulate(wv, mk()) for wv in waves[:60]]
+        trips = {}
+        for r in res:
+            for c, n in r[1].items():
+                trips[c] = trips.get(c, 0) + n / len(res)
+        tr = " ".join(f"{CL.get(c, {0:'BOX',3:'ENT',4:'EXT',5:'MED',6:'NOP',7:'END'}.get(c, c))}:{n:.0f}" for c, n in sorted(trips.items()))
+        print(f"   {pn:14s} cost {np.mean([r[0] for r in res]):8.0f}   trips {tr}")
+    nb = np.array([int((s == BOX).sum()) for s in secs])
+    mx = np.array([max(int((s == BOX).sum()) for s in wv) for wv in waves])
+    print("box steps per lane: mean %.1f median %.0f p90 %.0f max %d; mean of per-wave max %.1f" % (nb.mean(), np.median(nb), np.percentile(nb, 90), nb.max(), mx.mean()))
+    ln = np.array([len(s) for s in secs])
+    print("all steps per lane: mean %.1f p90 %.0f max %d" % (ln.mean(), np.percentile(ln, 90), ln.max()))
