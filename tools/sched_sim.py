@@ -145,7 +145,7 @@ def main():
     report("secondary", secs, "random")
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--refill", "--sort", "--phased")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--refill", "--sort", "--phased", "--threshold")):
     main()
 
 
@@ -303,3 +303,71 @@ if __name__ == "__main__" and "--phased" in sys.argv:
     print("box steps per lane: mean %.1f median %.0f p90 %.0f max %d; mean of per-wave max %.1f" % (nb.mean(), np.median(nb), np.percentile(nb, 90), nb.max(), mx.mean()))
     ln = np.array([len(s) for s in secs])
     print("all steps per lane: mean %.1f p90 %.0f max %d" % (ln.mean(), np.percentile(ln, 90), ln.max()))
+
+
+# Costs measured on the GPU (tools/prof_trips.py, wall cycles per trip with 4 waves per SIMD)
+MEASURED = {BOX: 772, ENTER: 2185, EXIT: 2185, MEDIUM: 2185, NOP: 2185, END: 2185, 33: 3191, 34: 3853, 35: 3083, 36: 3853, 37: 7296, 38: 1796, 39: 4801}
+
+
+def simulate_threshold_refill(seqs, lanes=64, threshold=32, sync_as_nop=True, refill_cost=3000):
+    """Persistent wave, phased policy; finished lanes wait until `threshold` lanes are idle (or nothing runs), then
+    all idle lanes take new rays in one refill event."""
+    pool = list(seqs)
+    nxt = 0
+    cur_seq = [None] * lanes
+    ptr = [0] * lanes
+    cost = 0
+    trips = {}
+    pol = PolPhased()
+    while True:
+        idle = [k for k in range(lanes) if cur_seq[k] is None or ptr[k] >= len(cur_seq[k])]
+        running = lanes - len(idle)
+        if nxt < len(pool) and (len(idle) >= threshold or running == 0):
+            for k in idle:
+                if nxt < len(pool):
+                    cur_seq[k] = pool[nxt]; nxt += 1; ptr[k] = 0
+            cost += refill_cost
+            trips["refill"] = trips.get("refill", 0) + 1
+            continue
+        cur = []
+        for k in range(lanes):
+            c = cur_seq[k][ptr[k]] if cur_seq[k] is not None and ptr[k] < len(cur_seq[k]) else None
+            if sync_as_nop and c == 38:
+                c = NOP
+            cur.append(c)
+        live = [c for c in cur if c is not None]
+        if not live:
+            break
+        counts = {}
+        for c in live:
+            counts[c] = counts.get(c, 0) + 1
+        pick = pol(counts, len(live))
+        for k, c in enumerate(cur):
+            if c == pick:
+                ptr[k] += 1
+        cost += MEASURED[pick]
+        trips[pick] = trips.get(pick, 0) + 1
+    return cost / len(pool) * 64, {c: n / len(pool) * 64 for c, n in trips.items()}
+
+
+if __name__ == "__main__" and "--threshold" in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    for label, seqs in (("primary", trace(desc, tiles)), ("secondary", trace(desc, sec))):
+        seqs = seqs[:64 * 100]
+        waves = [seqs[i:i + 64] for i in range(0, len(seqs) - 63, 64)]
+        COST.update(MEASURED); globals()['TRIP_OVERHEAD'] = 0
+        base = np.mean([simulate(wv, PolPhased())[0] for wv in waves])
+        print(f"{label}: phased, no refill: {base:.0f} cycles per 64 rays")
+        for th in (64, 48, 32, 16, 8, 1):
+            c, tr = simulate_threshold_refill(seqs, threshold=th)
+            print(f"   refill at >= {th:2d} idle lanes: {c:8.0f}   refills {tr.get('refill', 0):.1f} box trips {tr.get(BOX, 0):.0f}")
