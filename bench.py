@@ -56,6 +56,7 @@ def main():
 
     import torch
     import raytracing_rust_amd as rt
+    from raytracing_rust_amd import sharding
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,9 +82,8 @@ def main():
 
     def step(k):
         # row index unique per (rank, step); past the 70 rows of the stratification, wrap with another seed
-        row = rank * (args.steps + args.warmup) + k
-        opts = rt.render_opts(cam, sample_begin=(row % rows) * rows, sample_end=(row % rows + 1) * rows,
-                              seed=rt.scenes.PATH_SEED + row // rows, pipeline=args.pipeline)
+        b, e, seed = sharding.sample_row(rank, k, args.steps + args.warmup, rows, rt.scenes.PATH_SEED)
+        opts = rt.render_opts(cam, sample_begin=b, sample_end=e, seed=seed, pipeline=args.pipeline)
         scene.render_device(cam, opts, accum, stream)
 
     def fence():
@@ -101,8 +101,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
-    if dist is not None:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    sharding.reduce_sum(accum, dist, dst=0)
     if rank == 0:
         host = accum.cpu()
     fence()
