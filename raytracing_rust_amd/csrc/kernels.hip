@@ -40,6 +40,10 @@ using namespace rt;
 
 // ================================================================ kernels ===
 
+#ifndef RT_TRAV_THREADS
+#define RT_TRAV_THREADS 1024  // threads of a traversal workgroup (one workgroup per CU)
+#endif
+
 // ------------------------------------------------------- wavefront state ---
 // Paths in flight live in structure-of-arrays queues so that every load and store of a wave is one contiguous run.
 // f[k*cap + slot], k = 0..9: ray origin (3), ray direction (3), ray time, throughput (3).
@@ -58,75 +62,77 @@ struct WfCounters {
   uint32_t n_in;        // paths in the queue the traversal/shading kernels read
   uint32_t n_out;       // survivors appended to the other queue by the shading kernel
   uint32_t gen_count;   // camera paths to start in this iteration
-  uint32_t _pad;
-  unsigned long long gen_first, next_path, total_paths;
+  uint32_t gen_slot;    // queue slot of the first of them (they follow the survivors)
+  uint32_t gen_sample;  // sample offset of the first new path
+  uint32_t gen_rem;     // its pixel rank within that sample
+  unsigned long long next_path, total_paths;
 };
-struct WfFrame {       // what a path index means: pixel rectangle in 8x8 tiles x sample range
-  int x0, y0, x1, y1, tiles_x, sample_begin;
-  unsigned long long per_sample;  // tiles * 64
+struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
+  int x0, y0, w, h, sample_begin;
+  uint32_t per_sample;  // w * h
 };
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
-  c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_first = 0; c->next_path = 0; c->total_paths = total;
+  c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
+  c->next_path = 0; c->total_paths = total;
 }
 
-// One thread: decide how many new camera paths top the queue up and flip the in/out roles.
-__global__ void k_wf_prepare(WfCounters* c, uint32_t cap, unsigned long long* __restrict__ stats) {
+// One thread: decide how many new camera paths top the queue up and flip the in/out roles.  New paths take the
+// slots behind the survivors, so the ray generation kernel needs no atomics.
+__global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, unsigned long long* __restrict__ stats) {
   const uint32_t survivors = c->n_out;
   const unsigned long long remaining = c->total_paths - c->next_path;
   const unsigned long long room = cap - survivors;
-  const uint32_t g = (uint32_t)(remaining < room ? remaining : room);
-  c->gen_count = g; c->gen_first = c->next_path; c->next_path += g;
-  c->n_in = survivors;  // the ray generation kernel appends the valid new paths behind the survivors
+  uint32_t g = (uint32_t)(remaining < room ? remaining : room);
+  if ((unsigned long long)g < remaining) g &= ~63u;  // whole waves of new paths, except for the last ones
+  c->gen_count = g; c->gen_slot = survivors;
+  c->gen_sample = (uint32_t)(c->next_path / per_sample); c->gen_rem = (uint32_t)(c->next_path % per_sample);
+  c->next_path += g;
+  c->n_in = survivors + g;
   c->n_out = 0;
-  (void)stats;
+  stats[0] += g;  // only this single thread writes the path counter while a wavefront render runs
 }
 
-// Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, 8x8 tile, pixel in tile), so that the 64
-// lanes of a wave start the same stratified sample of neighbouring pixels.  Valid paths are appended to the queue
-// with one atomic per wave.
+// Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, pixel), pixels enumerated tile by tile
+// (8 x 8, clipped at the rectangle's edges) so that the 64 lanes of a wave start the same stratified sample of
+// neighbouring pixels.  Path k of the iteration goes to slot gen_slot + k.
 __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame fr, unsigned long long seed, uint32_t cap,
-                                                   WfCounters* c, WfQueue q, unsigned long long* __restrict__ stats) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63;
-  bool valid = false;
-  int i = 0, j = 0, s = 0;
-  if (idx < c->gen_count) {
-    const unsigned long long p = c->gen_first + idx;
-    const unsigned long long so = p / fr.per_sample, rem = p % fr.per_sample;
-    const uint32_t tile = (uint32_t)(rem >> 6), l = (uint32_t)(rem & 63);
-    s = fr.sample_begin + (int)so;
-    i = fr.x0 + (int)(tile % (uint32_t)fr.tiles_x) * 8 + (int)(l & 7);
-    j = fr.y0 + (int)(tile / (uint32_t)fr.tiles_x) * 8 + (int)(l >> 3);
-    valid = i < fr.x1 && j < fr.y1 && cam.max_depth > 0;
+                                                   const WfCounters* c, WfQueue q) {
+  const uint32_t count = c->gen_count, slot0 = c->gen_slot, s0 = c->gen_sample, r0 = c->gen_rem;
+  const uint32_t W = (uint32_t)fr.w, H = (uint32_t)fr.h;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
+    const uint32_t r = r0 + idx;                       // < per_sample + capacity, fits 32 bits (checked by the host)
+    const uint32_t so = r / fr.per_sample, rem = r - so * fr.per_sample;
+    const uint32_t row_px = W * 8u;
+    const uint32_t ty = rem / row_px, r2 = rem - ty * row_px;
+    const uint32_t hy = H - 8u * ty < 8u ? H - 8u * ty : 8u;
+    const uint32_t tile_px = 8u * hy;
+    uint32_t tx = r2 / tile_px;
+    if (tx > (W - 1u) / 8u) tx = (W - 1u) / 8u;
+    const uint32_t r3 = r2 - tx * tile_px;
+    const uint32_t wx = W - 8u * tx < 8u ? W - 8u * tx : 8u;
+    const uint32_t ly = r3 / wx, lx = r3 - ly * wx;
+    const int i = fr.x0 + (int)(8u * tx + lx), j = fr.y0 + (int)(8u * ty + ly);
+    const int s = fr.sample_begin + (int)(s0 + so);
+    const uint32_t slot = slot0 + idx;
+    const uint32_t pixel = (uint32_t)(j * cam.image_width + i);
+    PathRng rng = rng_make(seed, pixel, (uint32_t)s);
+    Ray ray = camera_ray(cam, i, j, s, rng);
+    double* f = q.f + slot;
+    f[0 * (size_t)cap] = ray.o.x; f[1 * (size_t)cap] = ray.o.y; f[2 * (size_t)cap] = ray.o.z;
+    f[3 * (size_t)cap] = ray.d.x; f[4 * (size_t)cap] = ray.d.y; f[5 * (size_t)cap] = ray.d.z;
+    f[6 * (size_t)cap] = ray.tm;
+    f[7 * (size_t)cap] = 1.0; f[8 * (size_t)cap] = 1.0; f[9 * (size_t)cap] = 1.0;
+    uint32_t* u = q.u + slot;
+    u[0] = pixel; u[(size_t)cap] = (uint32_t)s; u[2 * (size_t)cap] = (uint32_t)cam.max_depth << 16;
   }
-  const unsigned long long mask = __ballot(valid);
-  if (mask == 0) return;
-  uint32_t base = 0;
-  if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) {
-    base = atomicAdd(&c->n_in, (uint32_t)__popcll(mask));
-    atomicAdd(&stats[0], (unsigned long long)__popcll(mask));
-  }
-  base = __shfl(base, __ffsll((long long)mask) - 1);
-  if (!valid) return;
-  const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  const uint32_t pixel = (uint32_t)(j * cam.image_width + i);
-  PathRng rng = rng_make(seed, pixel, (uint32_t)s);
-  Ray r = camera_ray(cam, i, j, s, rng);
-  double* f = q.f + slot;
-  f[0 * (size_t)cap] = r.o.x; f[1 * (size_t)cap] = r.o.y; f[2 * (size_t)cap] = r.o.z;
-  f[3 * (size_t)cap] = r.d.x; f[4 * (size_t)cap] = r.d.y; f[5 * (size_t)cap] = r.d.z;
-  f[6 * (size_t)cap] = r.tm;
-  f[7 * (size_t)cap] = 1.0; f[8 * (size_t)cap] = 1.0; f[9 * (size_t)cap] = 1.0;
-  uint32_t* u = q.u + slot;
-  u[0] = pixel; u[(size_t)cap] = (uint32_t)s; u[2 * (size_t)cap] = (uint32_t)cam.max_depth << 16;
 }
 
 // Traversal kernel: one closest-hit query per queued path (world.hit, camera.rs:179).  Persistent 1024-thread
 // workgroups, one per CU: each stages the whole hit program (nodes + boxes) in LDS once, then walks its share of
 // the queue; only primitive records and the ray/hit streams touch global memory.
 template <bool USE_LDS>
-__global__ __launch_bounds__(1024) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, const WfCounters* c,
+__global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, const WfCounters* c,
                                                       WfQueue q, WfHits h, unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
   const uint32_t n = c->n_in;
@@ -213,14 +219,20 @@ __global__ __launch_bounds__(256) void k_wf_shade(Scene S, rtx_camera_desc cam, 
   uint32_t wp = probes;
   for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
   if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
-  // wave-ballot compaction of the survivors
+  // compaction of the survivors: ballot per wave, one atomic per workgroup
+  __shared__ uint32_t s_count[4], s_base;
   const unsigned long long mask = __ballot(alive);
-  if (mask == 0) return;
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(&c->n_out, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
+  const uint32_t wave = threadIdx.x >> 6;
+  if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+    s_base = total ? atomicAdd(&c->n_out, total) : 0u;
+  }
+  __syncthreads();
   if (!alive) return;
+  uint32_t base = s_base;
+  for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
   const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   double* f = qout.f + slot;
   f[0 * (size_t)cap] = next.o.x; f[1 * (size_t)cap] = next.o.y; f[2 * (size_t)cap] = next.o.z;
@@ -531,16 +543,18 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   if (st != RTX_OK) return st;
   const uint32_t cap = ctx->wf_cap;
   WfFrame fr;
-  fr.x0 = o->x0; fr.y0 = o->y0; fr.x1 = o->x1; fr.y1 = o->y1; fr.sample_begin = o->sample_begin;
-  fr.tiles_x = (o->x1 - o->x0 + 7) / 8;
-  const int tiles_y = (o->y1 - o->y0 + 7) / 8;
-  fr.per_sample = (unsigned long long)fr.tiles_x * (unsigned long long)tiles_y * 64ull;
-  const unsigned long long total = fr.per_sample * (unsigned long long)(o->sample_end - o->sample_begin);
+  fr.x0 = o->x0; fr.y0 = o->y0; fr.w = o->x1 - o->x0; fr.h = o->y1 - o->y0; fr.sample_begin = o->sample_begin;
+  const unsigned long long per_sample = (unsigned long long)fr.w * (unsigned long long)fr.h;
+  if (per_sample + cap >= (1ull << 32)) return fail(ctx, RTX_ERR_UNSUPPORTED, "rtx_render: more than 2^32 pixels in one call");
+  fr.per_sample = (uint32_t)per_sample;
+  // a path of depth 0 is black (camera.rs:169-171): nothing to trace
+  const unsigned long long total = cam->max_depth > 0 ? per_sample * (unsigned long long)(o->sample_end - o->sample_begin) : 0ull;
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
   const size_t prog_bytes = (size_t)sc->dev.n_units * 8;
   const bool use_lds = prog_bytes <= kLdsBudget;
   const unsigned blocks256 = cap / 256;
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
+  const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
   hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, stream, ctx->wf_c, total);
   const int chunk = 8;
   int cur = 0;  // queue the traversal reads in the next iteration
@@ -548,14 +562,14 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   for (int k = 0; !done; ++k) {
     for (int it = 0; it < chunk; ++it) {
       WfQueue qin = ctx->wf_q[cur], qout = ctx->wf_q[cur ^ 1];
-      hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, stream, ctx->wf_c, cap, ctx->d_counters);
-      hipLaunchKernelGGL(k_wf_raygen, dim3(blocks256), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin, ctx->d_counters);
+      hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, stream, ctx->wf_c, cap, fr.per_sample, ctx->d_counters);
+      hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin);
       TimedSpan sp;
       const bool timed = span_begin(ctx, stream, sp, 1);
       if (use_lds)
-        hipLaunchKernelGGL(k_wf_traverse<true>, dim3(trav_blocks), dim3(1024), prog_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+        hipLaunchKernelGGL(k_wf_traverse<true>, dim3(trav_blocks), dim3(RT_TRAV_THREADS), prog_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
       else
-        hipLaunchKernelGGL(k_wf_traverse<false>, dim3(trav_blocks), dim3(1024), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+        hipLaunchKernelGGL(k_wf_traverse<false>, dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
       if (timed) span_end(ctx, stream, sp);
       hipLaunchKernelGGL(k_wf_shade, dim3(blocks256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
       cur ^= 1;
