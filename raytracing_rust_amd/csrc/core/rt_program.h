@@ -11,6 +11,7 @@
 //   BOX6      idx = first of the six quads                     payload DBox6 (9 doubles)
 //   ENTER/EXIT idx = transform context, aux = op count         payload ops x {kind, a, b, c}
 //   MEDIUM    idx = medium, aux = first unit of its boundary   payload {neg_inv_density, needs_uv}
+//   MEDIUM_S  idx = medium whose boundary is one static sphere payload {neg_inv_density, needs_uv, DSphere}
 //   SPHERE, QUAD (moving spheres, general quads): no payload, the walker reads the ABI tables
 //   SYNC, NOP, END: no payload; an END closes the world program and every medium boundary program.
 //
@@ -34,6 +35,7 @@ struct CompiledProgram {
   std::vector<uint8_t> sphere_static, quad_aa;
   uint32_t world_begin = 0;
   uint32_t n_box6 = 0;
+  bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
   // a medium boundary).
@@ -118,6 +120,14 @@ struct CompiledProgram {
 
   struct Item { uint32_t kind, idx, count, node; DBox6 box6; };
 
+  // Is the boundary of medium m exactly one static sphere (in the medium's own transform context)?
+  bool sphere_bounded(const rtx_scene_desc& d, uint32_t m) const {
+    const rtx_medium& md = d.media[m];
+    if (md.b_end - md.b_begin != 1u) return false;
+    const uint32_t ki = d.nodes[md.b_begin].kind_idx;
+    return RTX_NODE_KIND(ki) == RTX_NODE_SPHERE && sphere_static[RTX_NODE_IDX(ki)];
+  }
+
   static uint32_t item_units(const rtx_scene_desc& d, const Item& it) {
     switch (it.kind) {
       case RTX_NODE_BOX: return PROG_BOX_UNITS;
@@ -126,6 +136,7 @@ struct CompiledProgram {
       case PROG_NODE_BOX6: return PROG_BOX6_UNITS;
       case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * d.xforms[it.idx].n_ops;
       case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
+      case PROG_NODE_MEDIUM_S: return PROG_MEDIUM_S_UNITS;
       default: return 1u;
     }
   }
@@ -153,6 +164,7 @@ struct CompiledProgram {
       const uint32_t idx = RTX_NODE_IDX(d.nodes[i].kind_idx);
       if (kind == RTX_NODE_SPHERE && sphere_static[idx]) kind = PROG_NODE_SPHERE_S;
       else if (kind == RTX_NODE_QUAD && quad_aa[idx]) kind = PROG_NODE_QUAD_AA;
+      else if (kind == RTX_NODE_MEDIUM && fuse_sphere_media && sphere_bounded(d, idx)) kind = PROG_NODE_MEDIUM_S;
       const bool run_kind = kind == PROG_NODE_SPHERE_S || kind == PROG_NODE_QUAD_AA;
       if (run_kind && !items.empty() && !target[i - b] && items.back().kind == kind &&
           items.back().idx + items.back().count == idx && items.back().node + items.back().count == i &&
@@ -230,6 +242,13 @@ struct CompiledProgram {
           uint64_t* r = u + 1 + PROG_XFORM_OP_UNITS * s;
           r[0] = (uint64_t)op.kind; r[1] = bits(op.a); r[2] = bits(op.b); r[3] = bits(op.c);
         }
+      } else if (it.kind == PROG_NODE_MEDIUM_S) {
+        const rtx_sphere& sp = d.spheres[RTX_NODE_IDX(d.nodes[d.media[it.idx].b_begin].kind_idx)];
+        const DSphere rec = {sp.c0[0], sp.c0[1], sp.c0[2], sp.radius};
+        u[0] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_MEDIUM_S, it.idx);
+        u[1] = bits(d.media[it.idx].neg_inv_density);
+        u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
+        memcpy(u + 3, &rec, sizeof(rec));
       } else if (it.kind == RTX_NODE_MEDIUM) {
         u[0] = (uint64_t)d.nodes[it.node].kind_idx | ((uint64_t)media[it.idx].b_begin << 32);
         u[1] = bits(d.media[it.idx].neg_inv_density);

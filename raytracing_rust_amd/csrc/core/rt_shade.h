@@ -199,6 +199,12 @@ RT_HD V3 lights_random(const Scene& S, const V3& origin, PathRng& rng) {
 
 // -------------------------------------------------------------- integrator ---
 
+// Optional cycle accounting of the shading code (a tuning build defines RT_SPROF; the product does not).
+#ifndef RT_SPROF
+#define RT_SPROF_START() do { } while (0)
+#define RT_SPROF(slot) do { } while (0)
+#endif
+
 struct PathState {
   V3 T;           // product of attenuation*spdf/pdf factors so far
   V3 L;           // radiance gathered so far
@@ -224,7 +230,8 @@ RT_HD double schlick(double cosine, double ratio) {
 // with `next`; false when it ended (ps.L is final).  A hit of kind NONE is a miss (camera.rs:179-181).
 RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, const Ray& wray,
                         const Hit& hit, const double* stale_uv, PathState& ps, Ray& next, uint32_t& probes) {
-  if (!hit_any(hit)) { ps.L = ps.L + cmul(ps.T, background); return false; }
+  RT_SPROF_START();
+  if (!hit_any(hit)) { ps.L = ps.L + cmul(ps.T, background); RT_SPROF(1); return false; }
   rng_stream(ps.rng, ps.bounce, RNG_DOMAIN_SHADE);
   const uint32_t hkind = RTX_NODE_KIND(hit.kind_idx);
   uint32_t mat_idx;
@@ -233,19 +240,24 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   else mat_idx = S.media[RTX_NODE_IDX(hit.kind_idx)].mat;
   const rtx_material m = S.materials[mat_idx];
   Surface sf;
+  RT_SPROF(2);
   resolve_hit(S, wray, hit, m.needs_uv != 0, stale_uv, sf);
+  RT_SPROF(3);
 
   // emission (camera.rs:184; diffuse_light.rs:37-39: both faces emit)
   if (m.kind == RTX_MAT_DIFFUSE_LIGHT) {
     V3 e = texture_value(S, m.tex, sf.u, sf.v, sf.p);
     ps.L = ps.L + cmul(ps.T, e);
+    RT_SPROF(4);
     return false;                                   // scatter() == false (camera.rs:188-190)
   }
   if (m.kind == RTX_MAT_NONE) return false;          // material.rs:74-76
 
   if (m.kind == RTX_MAT_METAL) {                     // metal.rs:25-37
+    RT_SPROF(15);
     V3 reflected = reflect(normalize(wray.d), sf.n);
     V3 dir = reflected + m.param * random_in_unit_sphere(ps.rng);
+    RT_SPROF(5);
     if (dot(dir, sf.n) <= 0.0) return false;
     ps.T = cmul(ps.T, v3(m.albedo));                 // camera.rs:193-200, no roulette on this branch
     next.o = sf.p; next.d = dir; next.tm = wray.tm;
@@ -253,6 +265,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
     return ps.depth > 0;                             // camera.rs:174-176: depth 0 contributes nothing
   }
   if (m.kind == RTX_MAT_DIELECTRIC) {                // dielectric.rs:31-54
+    RT_SPROF(15);
     double ri = sf.front ? 1.0 / m.param : m.param;
     V3 unit = normalize(wray.d);
     double cos_theta = fmin(dot(-unit, sf.n), 1.0);
@@ -262,13 +275,16 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
     if (cannot_refract || schlick(cos_theta, ri) > rng_next(ps.rng)) dir = reflect(unit, sf.n);
     else dir = refract(unit, sf.n, ri);
     next.o = sf.p; next.d = dir; next.tm = wray.tm;  // attenuation (1,1,1)
+    RT_SPROF(6);
     ps.depth -= 1; ps.bounce += 1;
     return ps.depth > 0;
   }
 
   // LAMBERTIAN (lambertian.rs:31-46) or ISOTROPIC (isotropic.rs:31-43)
   const bool lambert = m.kind == RTX_MAT_LAMBERTIAN;
+  RT_SPROF(15);
   V3 atten = texture_value(S, m.tex, sf.u, sf.v, sf.p);
+  RT_SPROF(7);
   Onb onb;
   if (lambert) onb = onb_from(sf.n);                 // CosinePDF::new, cosine_pdf.rs:14-18
 
@@ -280,6 +296,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   else if (lambert) dir = onb_local(onb, random_cosine_direction(ps.rng));   // cosine_pdf.rs:29-31
   else dir = random_unit_vector(ps.rng);                                     // sphere_pdf.rs:24-26
 
+  RT_SPROF(8);
   // density of that direction
   double mat_pdf;
   if (lambert) {                                     // cosine_pdf.rs:23-26
@@ -296,6 +313,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   } else {
     pdf_value = mat_pdf;
   }
+  RT_SPROF(9);
   if (pdf_value < 1e-6 || !isfinite(pdf_value)) return false;                // camera.rs:219-221
 
   double spdf;
@@ -314,6 +332,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   ps.T = cmul(ps.T, f / pdf_value);
   next.o = sf.p; next.d = dir; next.tm = wray.tm;   // camera.rs:223
   ps.depth -= 1; ps.bounce += 1;
+  RT_SPROF(10);
   return ps.depth > 0;
 }
 

@@ -61,12 +61,14 @@ struct Scene : rtx_scene_desc {
 #define PROG_BOX6_UNITS 10u      // header + DBox6
 #define PROG_XFORM_OP_UNITS 4u   // per transform op of an ENTER/EXIT record: kind, a, b, c
 #define PROG_MEDIUM_UNITS 3u     // header, neg_inv_density, needs_uv
+#define PROG_MEDIUM_S_UNITS 7u   // header, neg_inv_density, needs_uv, DSphere of the boundary
 #define PROG_NODE_NOP 6u         // filler
 #define PROG_NODE_END 7u         // end of a program (the world's, or a medium boundary's)
 #define PROG_NODE_SPHERE_S 8u    // run of static spheres, compact records (hits are reported as RTX_NODE_SPHERE)
 #define PROG_NODE_QUAD_AA 9u     // run of axis-aligned quads, compact records (hits are reported as RTX_NODE_QUAD)
 #define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
 #define PROG_NODE_BOX6 11u       // the six axis-aligned faces of a box_new box (hits are reported as RTX_NODE_QUAD)
+#define PROG_NODE_MEDIUM_S 12u   // a constant medium whose boundary is one static sphere, evaluated in one step
 
 // Units a record occupies, from its header unit.
 RT_HD uint32_t prog_record_units(uint64_t unit) {
@@ -78,6 +80,7 @@ RT_HD uint32_t prog_record_units(uint64_t unit) {
     case PROG_NODE_BOX6: return PROG_BOX6_UNITS;
     case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * aux;
     case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
+    case PROG_NODE_MEDIUM_S: return PROG_MEDIUM_S_UNITS;
     default: return 1u;
   }
 }
@@ -351,7 +354,7 @@ template <bool MEDIA, class RaySrc>
 RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                        double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                        double* stale_uv) {
-  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8 };
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8, CL_MEDIUM_S = 9 };
   uint32_t cur = 0;
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
@@ -378,6 +381,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
     else if (kind == RTX_NODE_QUAD) cls = CL_QUAD;
     else if (kind == PROG_NODE_SYNC) cls = CL_SYNC;
     else if (MEDIA && kind == PROG_NODE_END && mode == 2 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) cls = CL_MEDIUM_EVAL;
+    else if (MEDIA && kind == PROG_NODE_MEDIUM_S && use_media) cls = CL_MEDIUM_S;
     uint32_t next = i;  // unit to stand on after this trip
     if (RT_WAVE_ANY(running && cls == CL_CHEAP)) {
       RT_PROF_LANES(RT_WAVE_COUNT(running && cls == CL_CHEAP));
@@ -403,7 +407,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
           mode = 1; next = count; tmin = -RT_INF; tmax = RT_INF;
           hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
         } else {
-          next = i + (kind == RTX_NODE_MEDIUM ? PROG_MEDIUM_UNITS : 1u);  // a medium the query ignores, or filler
+          next = i + prog_record_units(unit);  // a medium the query ignores, or filler
         }
       }
       RT_PROF_TRIP(CL_CHEAP);
@@ -411,7 +415,7 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
       // 3. every running lane stands on a primitive (or waits at a SYNC): run the class most lanes wait for
       const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
       const int n_s = RT_WAVE_COUNT(running && cls == CL_SPHERE), n_q = RT_WAVE_COUNT(running && cls == CL_QUAD);
-      const int n_m = RT_WAVE_COUNT(running && cls == CL_MEDIUM_EVAL), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
+      const int n_m = RT_WAVE_COUNT(running && (cls == CL_MEDIUM_EVAL || cls == CL_MEDIUM_S)), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
       const int n_x = RT_WAVE_COUNT(running && cls == CL_BOX);
       int pick = CL_SYNC, best_n = 0;
       if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
@@ -489,28 +493,44 @@ RT_UNROLL
           next = i + size;
         }
       } else if (MEDIA) {
-        if (running && cls == CL_MEDIUM_EVAL) {      // constant_medium.rs:60-87, exit found at tmax
-          const double neg_inv_density = ((const double*)prog)[med_at + 1];
-          const bool needs_uv = prog[med_at + 2] != 0;
-          double t1 = fmax(t_entry, tmin0);
-          double t2 = fmin(tmax, out_tmax);
-          if (!(t1 >= t2)) {
-            t1 = fmax(t1, 0.0);
-            double ray_length = norm(lr.d);
-            double inside = (t2 - t1) * ray_length;
-            double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
-            double hit_distance = neg_inv_density * log(xi);
-            if (!(hit_distance > inside)) {
-              if (needs_uv && stale_uv) {
-                stale_uv[0] = 0.0; stale_uv[1] = 0.0;
-                if (RTX_NODE_KIND(out_kind) == RTX_NODE_SPHERE || RTX_NODE_KIND(out_kind) == RTX_NODE_QUAD) {
-                  Ray w;
-                  w.o = rs.origin(); w.d = rs.dir(); w.tm = tm;
-                  hit_uv(S, w, out_kind, out_ctx, out_tmax, stale_uv[0], stale_uv[1]);
+        // constant_medium.rs:60-87 once both boundary crossings are known.  MEDIUM_EVAL: the boundary program found
+        // the exit at tmax (entry in t_entry), the enclosing query waits in out_*.  MEDIUM_S: the boundary is one static
+        // sphere, so both crossings (entry over the whole line, exit after entry + 1e-4, constant_medium.rs:47-57) are
+        // computed here with the same sphere routine and the enclosing query is simply the current one.
+        const bool eval = running && cls == CL_MEDIUM_EVAL, direct = running && cls == CL_MEDIUM_S;
+        if (eval || direct) {
+          const uint32_t at = direct ? i : med_at;
+          double t_in = t_entry, t_out = tmax;
+          bool crossed = true;
+          if (direct) {
+            med = idx; ret_i = i + PROG_MEDIUM_S_UNITS; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
+            const DSphere sp = *(const DSphere*)(prog + i + 3);
+            crossed = sphere_s_hit_t(sp, lr.o, lr.d, -RT_INF, RT_INF, t_in) &&
+                      sphere_s_hit_t(sp, lr.o, lr.d, t_in + 0.0001, RT_INF, t_out);
+          }
+          if (crossed) {
+            const double neg_inv_density = ((const double*)prog)[at + 1];
+            const bool needs_uv = prog[at + 2] != 0;
+            double t1 = fmax(t_in, tmin0);
+            double t2 = fmin(t_out, out_tmax);
+            if (!(t1 >= t2)) {
+              t1 = fmax(t1, 0.0);
+              double ray_length = norm(lr.d);
+              double inside = (t2 - t1) * ray_length;
+              double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
+              double hit_distance = neg_inv_density * log(xi);
+              if (!(hit_distance > inside)) {
+                if (needs_uv && stale_uv) {
+                  stale_uv[0] = 0.0; stale_uv[1] = 0.0;
+                  if (RTX_NODE_KIND(out_kind) == RTX_NODE_SPHERE || RTX_NODE_KIND(out_kind) == RTX_NODE_QUAD) {
+                    Ray w;
+                    w.o = rs.origin(); w.d = rs.dir(); w.tm = tm;
+                    hit_uv(S, w, out_kind, out_ctx, out_tmax, stale_uv[0], stale_uv[1]);
+                  }
                 }
+                out_tmax = t1 + hit_distance / ray_length;
+                out_kind = RTX_NODE_MAKE(RTX_NODE_MEDIUM, med); out_ctx = ret_cur;
               }
-              out_tmax = t1 + hit_distance / ray_length;
-              out_kind = RTX_NODE_MAKE(RTX_NODE_MEDIUM, med); out_ctx = ret_cur;
             }
           }
           mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;

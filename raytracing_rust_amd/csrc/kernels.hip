@@ -16,6 +16,7 @@
 // Tuning build only (make prof): cycles, trips and lanes per class of the traversal loop.  Wave leaders accumulate
 // in LDS; the traversal kernel flushes the block's sums to g_prof once, when it ends.
 __device__ unsigned long long g_prof[64];
+__device__ unsigned long long g_sprof[32];
 __shared__ unsigned long long g_prof_lds[16 * 30];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_PROF_START() long long prof_t0 = clock64(); int prof_lanes = 0; (void)prof_lanes
@@ -31,6 +32,18 @@ __shared__ unsigned long long g_prof_lds[16 * 30];
     }                                                                            \
     prof_t0 = clock64();                                                         \
   } while (0)
+// shading kernel: sections of shade_bounce, measured by the first active lane of the wave, one block in eight
+#define RT_SPROF_START() long long sprof_t0 = clock64()
+#define RT_SPROF(slot)                                                           \
+  do {                                                                           \
+    const long long t1_ = clock64();                                             \
+    const unsigned long long m_ = __ballot(1);                                   \
+    if ((blockIdx.x & 7u) == 0 && (int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1) { \
+      atomicAdd(&g_sprof[(slot)], (unsigned long long)(t1_ - sprof_t0));         \
+      atomicAdd(&g_sprof[16 + (slot)], 1ull);                                    \
+    }                                                                            \
+    sprof_t0 = clock64();                                                        \
+  } while (0)
 #endif
 #endif
 #include "core/rt_program.h"
@@ -40,6 +53,9 @@ using namespace rt;
 
 // ================================================================ kernels ===
 
+#ifndef RT_SHADE_ATTR
+#define RT_SHADE_ATTR
+#endif
 #ifndef RT_TRAV_THREADS
 #define RT_TRAV_THREADS 1024  // threads of a traversal workgroup (one workgroup per CU)
 #endif
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
 // Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
 // ends adds throughput x radiance to its pixel; a path that goes on is appended to the other queue, compacted with
 // one ballot and one atomic per wave, so dead lanes never reach the next traversal.
-__global__ __launch_bounds__(256) void k_wf_shade(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
+__global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
                                                   int use_lights, WfCounters* c, WfQueue qin, WfHits h, WfQueue qout,
                                                   double* __restrict__ accum, unsigned long long* __restrict__ stats) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,6 +819,14 @@ extern "C" int rtx_debug_prof_read(unsigned long long* out64, int reset) {
   if (reset) {
     unsigned long long zero[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+extern "C" int rtx_debug_sprof_read(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sprof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), zero, sizeof(zero)) != hipSuccess) return -1;
   }
   return 0;
 }

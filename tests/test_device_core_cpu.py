@@ -160,3 +160,25 @@ def test_sample_ranges_and_tiles_add_up():
         p, _ = H.hostsim_render(desc, cam, o, threads=1)
         tiles += p
     assert np.array_equal(tiles, whole)
+
+
+@pytest.mark.parametrize("name,width", [("final", 40), ("smoke", 32)])
+def test_sphere_bounded_media_in_one_step_are_bit_identical(name, width):
+    """A medium whose boundary is one static sphere is compiled into a single unit that computes both boundary
+    crossings itself (constant_medium.rs:47-57); the render must not change by a bit against the generic form that
+    runs the boundary program twice.  (`smoke` has box-bounded media: both builds take the generic form.)"""
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=width, spp=16, depth=12)
+    desc = rt.flatten(g, w, l)
+    opts = rt.render_opts(cam, sample_begin=0, sample_end=16, seed=6)
+    lib = H.hostsim_lib()
+    try:
+        lib.sim_set_fuse_sphere_media(0)
+        a, ca = H.hostsim_render(desc, cam, opts)
+        lib.sim_set_fuse_sphere_media(1)
+        b, cb = H.hostsim_render(desc, cam, opts)
+    finally:
+        lib.sim_set_fuse_sphere_media(1)
+    assert ca == cb
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert a.sum() > 0
