@@ -530,7 +530,7 @@ static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, 
 
 static rtx_status wf_ensure(rtx_context* ctx) {
   if (ctx->wf_cap) return RTX_OK;
-  uint32_t cap = 1u << 21;
+  uint32_t cap = 1u << 23;  // paths in flight: 1.8 GB of queues; measured plateau of throughput vs. capacity
   if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
   cap = (cap + 255u) & ~255u;
   auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) ctx->wf_allocs.push_back(*p); return e; };
