@@ -202,14 +202,17 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
 __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
                                                   int use_lights, WfCounters* c, WfQueue qin, WfHits h, WfQueue qout,
                                                   double* __restrict__ accum, unsigned long long* __restrict__ stats) {
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t n = c->n_in;
-  if (blockIdx.x * blockDim.x >= n) return;
+  uint32_t probes = 0;
+  __shared__ uint32_t s_count[4], s_base;
+  // grid-stride over the queue: the trip count is the same for every thread of a workgroup
+  for (uint32_t first = blockIdx.x * blockDim.x; first < n; first += gridDim.x * blockDim.x) {
+  const uint32_t idx = first + threadIdx.x;
   bool alive = false;
   PathState ps;
   Ray next;
-  uint32_t pixel = 0, sample = 0, probes = 0;
+  uint32_t pixel = 0, sample = 0;
   if (idx < n) {
     const double* f = qin.f + idx;
     Ray ray;
@@ -231,12 +234,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
       unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
     }
   }
-  // light-probe statistics: one atomic per wave
-  uint32_t wp = probes;
-  for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
-  if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
   // compaction of the survivors: ballot per wave, one atomic per workgroup
-  __shared__ uint32_t s_count[4], s_base;
   const unsigned long long mask = __ballot(alive);
   const uint32_t wave = threadIdx.x >> 6;
   if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
@@ -246,17 +244,24 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
     s_base = total ? atomicAdd(&c->n_out, total) : 0u;
   }
   __syncthreads();
-  if (!alive) return;
-  uint32_t base = s_base;
-  for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
-  const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  double* f = qout.f + slot;
-  f[0 * (size_t)cap] = next.o.x; f[1 * (size_t)cap] = next.o.y; f[2 * (size_t)cap] = next.o.z;
-  f[3 * (size_t)cap] = next.d.x; f[4 * (size_t)cap] = next.d.y; f[5 * (size_t)cap] = next.d.z;
-  f[6 * (size_t)cap] = next.tm;
-  f[7 * (size_t)cap] = ps.T.x; f[8 * (size_t)cap] = ps.T.y; f[9 * (size_t)cap] = ps.T.z;
-  uint32_t* u = qout.u + slot;
-  u[0] = pixel; u[(size_t)cap] = sample; u[2 * (size_t)cap] = ((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu);
+  if (alive) {
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
+    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    double* f = qout.f + slot;
+    f[0 * (size_t)cap] = next.o.x; f[1 * (size_t)cap] = next.o.y; f[2 * (size_t)cap] = next.o.z;
+    f[3 * (size_t)cap] = next.d.x; f[4 * (size_t)cap] = next.d.y; f[5 * (size_t)cap] = next.d.z;
+    f[6 * (size_t)cap] = next.tm;
+    f[7 * (size_t)cap] = ps.T.x; f[8 * (size_t)cap] = ps.T.y; f[9 * (size_t)cap] = ps.T.z;
+    uint32_t* u = qout.u + slot;
+    u[0] = pixel; u[(size_t)cap] = sample; u[2 * (size_t)cap] = ((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu);
+  }
+  __syncthreads();  // s_count / s_base are reused by the next trip
+  }
+  // light-probe statistics: one atomic per wave
+  uint32_t wp = probes;
+  for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
+  if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
 }
 
 // ------------------------------------------------------------ fused path ---
@@ -571,6 +576,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const unsigned blocks256 = cap / 256;
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
   const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
+  const unsigned shade_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 16u);
   hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, stream, ctx->wf_c, total);
   const int chunk = 8;
   int cur = 0;  // queue the traversal reads in the next iteration
@@ -587,7 +593,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       else
         hipLaunchKernelGGL(k_wf_traverse<false>, dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
       if (timed) span_end(ctx, stream, sp);
-      hipLaunchKernelGGL(k_wf_shade, dim3(blocks256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
+      hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
       cur ^= 1;
     }
     HIP_TRY(ctx, hipGetLastError());
