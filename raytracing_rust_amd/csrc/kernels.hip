@@ -81,6 +81,8 @@ struct WfCounters {
   uint32_t gen_slot;    // queue slot of the first of them (they follow the survivors)
   uint32_t gen_sample;  // sample offset of the first new path
   uint32_t gen_rem;     // its pixel rank within that sample
+  uint32_t finished;    // set by k_wf_finish: the survivors have been run to their end
+  uint32_t _pad;
   unsigned long long next_path, total_paths;
 };
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
@@ -90,13 +92,15 @@ struct WfFrame {       // what a path index means: (sample offset, pixel rank); 
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
+  c->finished = 0; c->_pad = 0;
   c->next_path = 0; c->total_paths = total;
 }
 
 // One thread: decide how many new camera paths top the queue up and flip the in/out roles.  New paths take the
 // slots behind the survivors, so the ray generation kernel needs no atomics.
 __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, unsigned long long* __restrict__ stats) {
-  const uint32_t survivors = c->n_out;
+  const uint32_t survivors = c->finished ? 0u : c->n_out;
+  c->finished = 0;
   const unsigned long long remaining = c->total_paths - c->next_path;
   const unsigned long long room = cap - survivors;
   uint32_t g = (uint32_t)(remaining < room ? remaining : room);
@@ -262,6 +266,60 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t wp = probes;
   for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
   if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
+}
+
+// Tail of a render call.  Once no new camera paths are left and only a few survivors remain, an iteration of three
+// launches per bounce is all launch latency.  This kernel takes the survivors (at most `threshold`) and runs every one
+// of them to its end in place: closest hit + shading in a loop, the program read from global memory.  It is launched
+// after every chunk of iterations and does nothing until that moment; afterwards the queue is empty.
+__global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
+                                                   int use_lights, uint32_t threshold, WfCounters* c, WfQueue qin,
+                                                   double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+  const uint32_t n = c->n_out;  // survivors of the last shading launch
+  if (n == 0 || n > threshold || c->next_path != c->total_paths) return;
+  if (blockIdx.x * blockDim.x >= n) return;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const V3 bg = v3(cam.background);
+  bool alive = idx < n;
+  const uint32_t ld = alive ? idx : 0;
+  const double* f = qin.f + ld;
+  Ray ray;
+  ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
+  ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
+  ray.tm = f[6 * (size_t)cap];
+  PathState ps;
+  ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
+  ps.L = v3(0.0, 0.0, 0.0);
+  const uint32_t* u = qin.u + ld;
+  const uint32_t pixel = u[0], sample = u[(size_t)cap], db = u[2 * (size_t)cap];
+  ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
+  ps.rng = rng_make(seed, pixel, sample);
+  uint32_t segs = 0, probes = 0;
+  while (__any(alive)) {  // the wave leaves together: the traversal votes across all 64 lanes
+    Hit hit;
+    double stale_uv[2] = {0.0, 0.0};
+    if (alive) ++segs;
+    RayRegs rs;
+    rs.r = ray;
+    closest_hit<true>(S, S.prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, S.n_media != 0, ps.rng, ps.bounce, stale_uv);
+    if (alive) {
+      Ray next;
+      ps.L = v3(0.0, 0.0, 0.0);
+      alive = shade_bounce(S, bg, use_lights != 0, ray, hit, stale_uv, ps, next, probes);
+      ray = next;
+      if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
+        double* a = accum + (size_t)pixel * 3;
+        unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
+      }
+    }
+  }
+  __shared__ unsigned int sh[2];
+  if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+  __syncthreads();
+  atomicAdd(&sh[0], segs); atomicAdd(&sh[1], probes);
+  __syncthreads();
+  if (threadIdx.x < 2 && sh[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->finished = 1u;  // the next k_wf_prepare drops the survivors
 }
 
 // ------------------------------------------------------------ fused path ---
@@ -558,6 +616,8 @@ static rtx_status wf_ensure(rtx_context* ctx) {
 // The wavefront loop: [prepare, ray generation, traversal, shading+compaction] per iteration until every camera path
 // of the call has ended.  Iterations are enqueued in chunks; the counters of chunk k are inspected while chunk k+1 is
 // already enqueued, so the GPU never waits for the host.  Kernels of an iteration with nothing to do exit at once.
+static const unsigned kFinishThreshold = 64 * 1024;  // survivors k_wf_finish takes over (a multiple of 256)
+
 static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
   rtx_context* ctx = sc->ctx;
   rtx_status st = wf_ensure(ctx);
@@ -596,6 +656,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
       cur ^= 1;
     }
+    hipLaunchKernelGGL(k_wf_finish, dim3(kFinishThreshold / 256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, (uint32_t)kFinishThreshold, ctx->wf_c, ctx->wf_q[cur], accum_dev, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->wf_host[k & 1], ctx->wf_c, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[k & 1], stream));
