@@ -3,10 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over one batch: every pixel of the 800x800 frame traced for one row of the 70x70
-stratification (70 consecutive sample indices), i.e. 44.8 M camera paths.  Rank r takes its own disjoint sample rows
-(weak scaling: per-GPU work is fixed), all ranks' accumulators are summed on rank 0 with one reduce (RCCL) inside
-the timed region, and rank 0 copies the sum to the host.  Prints ONE JSON line on rank 0.
+A step is one pass of the hot path over one batch: ONE render call of the whole configuration the metric is quoted on,
+every pixel of the 800x800 frame traced for all 70 x 70 = 4900 stratified sample indices (3.136 G camera paths;
+`--rows R` renders R of the 70 rows per step instead).  Every (rank, step) gets its own path seed (weak scaling:
+per-GPU work is fixed), all ranks' accumulators are summed on rank 0 with one reduce (RCCL) inside the timed region,
+and rank 0 copies the sum to the host.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -52,7 +53,8 @@ def cpu_baseline(threads, rows=1, samples=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=70, help="rows of the 70x70 stratification per step (a divisor of 70)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,8 +88,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(k):
-        # row index unique per (rank, step); past the 70 rows of the stratification, wrap with another seed
-        b, e, seed = sharding.sample_row(rank, k, args.steps + args.warmup, rows, rt.scenes.PATH_SEED)
+        # batch unique per (rank, step); past the 70 rows of the stratification, go on with another seed
+        b, e, seed = sharding.sample_batch(rank, k, args.steps + args.warmup, rows, rt.scenes.PATH_SEED, args.rows)
         opts = rt.render_opts(cam, sample_begin=b, sample_end=e, seed=seed, pipeline=args.pipeline)
         scene.render_device(cam, opts, accum, stream)
 
@@ -123,7 +125,7 @@ def main():
 
     if rank == 0:
         assert bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
-        assert paths == npix * rows * args.steps * world_size
+        assert paths == npix * rows * args.rows * args.steps * world_size
         # HIP events around every k_wf_traverse launch, recorded by the library on the stream it launches on (rank 0)
         fused = st["traverse_launches"] == 0
         n_launch = st["launches"] if fused else st["traverse_launches"]
@@ -135,8 +137,9 @@ def main():
             "metric": "Msamples/s (node) final scene 800x800", "value": paths / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "final scene (final_scene.rs) 800x800, depth 75, step = 70 sample indices/pixel of the "
-                                   "4900-sample stratification = 44.8M camera paths per GPU per step",
+            "config": {"workload": f"final scene (final_scene.rs) 800x800, depth 75, step = one render call of {args.rows} of the "
+                                   f"70 rows of the 4900-sample stratification = {npix * rows * args.rows / 1e6:.1f}M camera "
+                                   "paths per GPU per step",
                        "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator"},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

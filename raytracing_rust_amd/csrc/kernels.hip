@@ -616,7 +616,11 @@ static rtx_status wf_ensure(rtx_context* ctx) {
 // The wavefront loop: [prepare, ray generation, traversal, shading+compaction] per iteration until every camera path
 // of the call has ended.  Iterations are enqueued in chunks; the counters of chunk k are inspected while chunk k+1 is
 // already enqueued, so the GPU never waits for the host.  Kernels of an iteration with nothing to do exit at once.
-static const unsigned kFinishThreshold = 64 * 1024;  // survivors k_wf_finish takes over (a multiple of 256)
+static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
+  static unsigned v = 0;
+  if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
+  return v;
+}
 
 static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
   rtx_context* ctx = sc->ctx;
@@ -656,7 +660,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
       cur ^= 1;
     }
-    hipLaunchKernelGGL(k_wf_finish, dim3(kFinishThreshold / 256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, (uint32_t)kFinishThreshold, ctx->wf_c, ctx->wf_q[cur], accum_dev, ctx->d_counters);
+    hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, (uint32_t)finish_threshold(), ctx->wf_c, ctx->wf_q[cur], accum_dev, ctx->d_counters);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(&ctx->wf_host[k & 1], ctx->wf_c, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[k & 1], stream));

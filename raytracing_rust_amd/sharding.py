@@ -6,12 +6,22 @@ the sum over ranks is the image.  Units of work are ROWS of the sqrt_spp x sqrt_
 sample indices [r * sqrt_spp, (r + 1) * sqrt_spp)."""
 
 
+def sample_batch(rank, step, steps_per_rank, sqrt_spp, base_seed, rows_per_step):
+    """The batch of `rows_per_step` rows that `rank` renders in its `step`-th step, as (sample_begin, sample_end,
+    seed).  Batches are disjoint over (rank, step); past the sqrt_spp rows of one stratification the next one starts
+    with another seed.  rows_per_step must divide sqrt_spp."""
+    if rows_per_step < 1 or sqrt_spp % rows_per_step:
+        raise ValueError("rows_per_step must divide sqrt_spp")
+    per_strat = sqrt_spp // rows_per_step
+    batch = rank * steps_per_rank + step
+    r = batch % per_strat
+    begin = r * rows_per_step * sqrt_spp
+    return begin, begin + rows_per_step * sqrt_spp, base_seed + batch // per_strat
+
+
 def sample_row(rank, step, steps_per_rank, sqrt_spp, base_seed):
-    """The row that `rank` renders in its `step`-th step, as (sample_begin, sample_end, seed).  Rows are disjoint over
-    (rank, step); past the sqrt_spp rows of one stratification the next one starts with another seed."""
-    row = rank * steps_per_rank + step
-    r = row % sqrt_spp
-    return r * sqrt_spp, (r + 1) * sqrt_spp, base_seed + row // sqrt_spp
+    """sample_batch with one row per step."""
+    return sample_batch(rank, step, steps_per_rank, sqrt_spp, base_seed, 1)
 
 
 def rank_rows(rank, world_size, n_rows):
