@@ -82,6 +82,27 @@ def test_render_matches_oracle_statistically(gpu_ctx, name, spp, depth):
     scene.close()
 
 
+@pytest.mark.parametrize("name,width,spp", [("final", 200, 16), ("smoke", 120, 16), ("cornell", 120, 16)])
+def test_wavefront_and_fused_pipelines_trace_the_same_paths(gpu_ctx, name, width, spp):
+    """Both pipelines address the RNG by (pixel, sample, bounce), so they trace identical paths: the accumulators
+    agree up to the order of the f64 additions (tolerance 1e-11 relative, stated here), and so do the segment and
+    light-probe counters.  Covers what only the wavefront path has: queues, compaction, deferred sections, the tail
+    kernel."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build(name, gp, width=width, spp=spp, depth=40)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    out = {}
+    for pipe in (_capi.PIPELINE_FUSED, _capi.PIPELINE_WAVEFRONT):
+        gpu_ctx.reset_stats()
+        out[pipe] = (scene.render(cam, rt.render_opts(cam, seed=77, pipeline=pipe)), gpu_ctx.stats())
+    (a, sa), (b, sb) = out[_capi.PIPELINE_FUSED], out[_capi.PIPELINE_WAVEFRONT]
+    assert sa["paths"] == sb["paths"] == cam.image_width * cam.image_height * cam.sqrt_spp ** 2
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    assert a.sum() > 0
+    scene.close()
+
+
 def test_sample_ranges_and_rectangles_add_up(gpu_ctx):
     """Sharding property: disjoint sample ranges and pixel rectangles sum to the full render (RNG streams are keyed
     by (pixel, sample), so the shards trace exactly the same paths)."""
