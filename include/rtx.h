@@ -191,8 +191,10 @@ typedef struct rtx_stats { /* totals since context creation */
   double render_ms;      /* stream time of render calls (HIP events around each call) */
   uint64_t launches;     /* number of render calls */
   double last_kernel_ms; /* device time of the most recent render call */
-  double traverse_ms;    /* device time of traversal-kernel launches (wavefront pipeline, HIP events) */
+  double traverse_ms;    /* device time of the world-program traversal launches (wavefront pipeline, HIP events) */
   uint64_t traverse_launches;
+  double tail_ms;        /* device time of the deferred-section traversal launches, when the program has one */
+  uint64_t tail_launches;
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;

@@ -36,6 +36,9 @@ struct CompiledProgram {
   uint32_t world_begin = 0;
   uint32_t n_box6 = 0;
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
+  bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
+  uint32_t tail_begin = 0;         // first unit of that program, 0 = none
+  uint32_t defer_pos = 0;          // unit index of the DEFER unit
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
   // a medium boundary).
@@ -48,7 +51,34 @@ struct CompiledProgram {
       media[m].b_begin = emit_range(d, d.media[m].b_begin, d.media[m].b_end, false);
       media[m].b_end = 0;
     }
-    world_begin = emit_range(d, d.world_begin, d.world_end, true);
+    tail_begin = 0;
+    uint32_t root = 0, ctx = 0;
+    bool has_xf = false;
+    if (defer_last_section && find_deferrable(d, root, has_xf, ctx)) {
+      // world program with a DEFER node in place of the subtree under `root`
+      const uint32_t skip = d.nodes[root].skip;
+      // (appended behind a copy of all nodes, so that every other index of the description stays valid)
+      std::vector<rtx_node> nodes(d.nodes, d.nodes + d.n_nodes);
+      const uint32_t mb = d.n_nodes, shift = mb - d.world_begin;
+      for (uint32_t k = d.world_begin; k <= root; ++k) {
+        rtx_node nd = d.nodes[k];
+        if (RTX_NODE_KIND(nd.kind_idx) == RTX_NODE_BOX) nd.skip += shift;
+        nodes.push_back(nd);
+      }
+      nodes.back().skip = (uint32_t)nodes.size() + 1u;                    // the root box skips the DEFER node
+      nodes.push_back(rtx_node{RTX_NODE_MAKE(PROG_NODE_DEFER, 0), 0});
+      nodes.insert(nodes.end(), d.nodes + skip, d.nodes + d.world_end);   // only EXIT nodes follow: no links to fix
+      rtx_scene_desc dm = d;
+      dm.nodes = nodes.data(); dm.n_nodes = (uint32_t)nodes.size();
+      world_begin = emit_range(dm, mb, (uint32_t)nodes.size(), true);
+      if (units.size() & 1u) units.push_back(nop());  // the deferred program starts on a 16-byte boundary
+      tail_begin = (uint32_t)units.size();
+      if (has_xf) emit_enter(d, ctx);
+      emit_range(d, root + 1, skip, false);
+      units[defer_pos] |= (uint64_t)tail_begin << 32;  // the DEFER unit learns where the section's program starts
+    } else {
+      world_begin = emit_range(d, d.world_begin, d.world_end, true);
+    }
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
   }
@@ -60,7 +90,7 @@ struct CompiledProgram {
     S.nodes = nullptr; S.n_nodes = 0;
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
-    S.prog = units.data(); S.n_units = (uint32_t)units.size(); S._pad1 = 0;
+    S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
     return S;
   }
 
@@ -119,6 +149,65 @@ struct CompiledProgram {
   }
 
   struct Item { uint32_t kind, idx, count, node; DBox6 box6; };
+
+  // Is the last top-level item of the world a box subtree, possibly inside one ENTER/EXIT pair, that is worth a
+  // program of its own?  root = its root BOX node.  Media inside are excluded (their boundary programs live with the
+  // world program).
+  static bool find_deferrable(const rtx_scene_desc& d, uint32_t& root, bool& has_xf, uint32_t& ctx) {
+    uint32_t i = d.world_begin, last = d.world_begin;
+    while (i < d.world_end) {
+      last = i;
+      const uint32_t kind = RTX_NODE_KIND(d.nodes[i].kind_idx);
+      if (kind == RTX_NODE_BOX) {
+        i = d.nodes[i].skip;
+      } else if (kind == RTX_NODE_ENTER) {
+        int depth = 1;
+        for (++i; i < d.world_end && depth > 0; ++i) {
+          const uint32_t k = RTX_NODE_KIND(d.nodes[i].kind_idx);
+          if (k == RTX_NODE_ENTER) ++depth;
+          else if (k == RTX_NODE_EXIT) --depth;
+        }
+      } else {
+        ++i;
+      }
+    }
+    if (d.world_end <= d.world_begin) return false;
+    const uint32_t kind = RTX_NODE_KIND(d.nodes[last].kind_idx);
+    uint32_t end = d.world_end;
+    if (kind == RTX_NODE_BOX) {
+      root = last; has_xf = false; ctx = 0;
+    } else if (kind == RTX_NODE_ENTER) {
+      // k nested transforms around the subtree: k ENTER nodes, the root box, ..., k EXIT nodes.  A context is the whole
+      // chain from the world, so the innermost ENTER alone sets up the section's program.
+      uint32_t k = 0;
+      while (last + k < d.world_end && RTX_NODE_KIND(d.nodes[last + k].kind_idx) == RTX_NODE_ENTER) ++k;
+      if (last + k >= d.world_end || d.world_end - last < 2 * k + 1) return false;
+      if (RTX_NODE_KIND(d.nodes[last + k].kind_idx) != RTX_NODE_BOX) return false;
+      for (uint32_t j = 0; j < k; ++j)
+        if (RTX_NODE_KIND(d.nodes[d.world_end - 1 - j].kind_idx) != RTX_NODE_EXIT) return false;
+      root = last + k; has_xf = true; ctx = RTX_NODE_IDX(d.nodes[last + k - 1].kind_idx); end = d.world_end - k;
+    } else {
+      return false;
+    }
+    if (d.nodes[root].skip != end) return false;
+    uint32_t boxes = 0;
+    for (uint32_t k = root + 1; k < end; ++k) {
+      const uint32_t kk = RTX_NODE_KIND(d.nodes[k].kind_idx);
+      if (kk == RTX_NODE_MEDIUM) return false;
+      if (kk == RTX_NODE_BOX) ++boxes;
+    }
+    return boxes >= 32;
+  }
+
+  // ENTER record of transform context `ctx` (header + op chain).
+  void emit_enter(const rtx_scene_desc& d, uint32_t ctx) {
+    const rtx_xform x = d.xforms[ctx];
+    units.push_back((uint64_t)RTX_NODE_MAKE(RTX_NODE_ENTER, ctx) | ((uint64_t)x.n_ops << 32));
+    for (uint32_t s = 0; s < x.n_ops; ++s) {
+      const rtx_xform_op op = d.xform_ops[x.first_op + s];
+      units.push_back((uint64_t)op.kind); units.push_back(bits(op.a)); units.push_back(bits(op.b)); units.push_back(bits(op.c));
+    }
+  }
 
   // Is the boundary of medium m exactly one static sphere (in the medium's own transform context)?
   bool sphere_bounded(const rtx_scene_desc& d, uint32_t m) const {
@@ -255,6 +344,7 @@ struct CompiledProgram {
         u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
       } else {
         u[0] = (uint64_t)d.nodes[it.node].kind_idx;
+        if (it.kind == PROG_NODE_DEFER) defer_pos = p;
       }
     }
     if (sync_before[n]) units[link[n]] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_SYNC, 0);

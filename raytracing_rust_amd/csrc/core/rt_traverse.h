@@ -52,7 +52,9 @@ RT_HD DAAQuad box6_face(const DBox6& r, int f) {
 // program (rt_program.h).  world_begin and media[].b_begin are UNIT indices into `prog` here.
 struct Scene : rtx_scene_desc {
   const uint64_t* prog;
-  uint32_t n_units, _pad1;
+  uint32_t n_units;
+  uint32_t tail_begin;  // first unit of the deferred section's program (0 = the world program has none); the units
+                        // before it are all a walk with DEFER = true can reach
 };
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
@@ -69,6 +71,7 @@ struct Scene : rtx_scene_desc {
 #define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
 #define PROG_NODE_BOX6 11u       // the six axis-aligned faces of a box_new box (hits are reported as RTX_NODE_QUAD)
 #define PROG_NODE_MEDIUM_S 12u   // a constant medium whose boundary is one static sphere, evaluated in one step
+#define PROG_NODE_DEFER 13u      // behind the root box of the deferred section; aux = first unit of that section's program
 
 // Units a record occupies, from its header unit.
 RT_HD uint32_t prog_record_units(uint64_t unit) {
@@ -350,12 +353,21 @@ struct RayMem {       // structure-of-arrays queue: f[k*cap], k = 0..5
 // counter, so it does not depend on how paths are scheduled.  stale_uv (2 doubles, may be null) receives the
 // (u,v) the reference's record still holds when a medium whose phase texture reads them scatters
 // (constant_medium.rs:81-87 leaves u,v untouched).
-template <bool MEDIA, class RaySrc>
-RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
-                       double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
-                       double* stale_uv) {
+//
+// Deferred section.  The program compiler may move the last top-level box subtree of the world (with its transform)
+// into a program of its own and leave a DEFER unit behind the subtree's root box (rt_program.h).  With DEFER = false
+// the unit is a call: the walk continues in that program and comes back at its END, i.e. the walk is the reference's.
+// With DEFER = true the walk notes that the ray passed the root box, skips the section and returns true; the caller
+// runs the section later (same ray, tmax0 = the t found so far), which is the same walk cut in two because the
+// section is the last thing the world program visits.
+template <bool MEDIA, bool DEFER, class RaySrc>
+RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
+                        double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
+                        double* stale_uv) {
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8, CL_MEDIUM_S = 9 };
   uint32_t cur = 0;
+  uint32_t ret_tail = 0;  // DEFER = false: where to continue after the deferred program's END (0 = not inside it)
+  bool deferred = false;
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
   if (active) lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
@@ -389,7 +401,8 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
       if (running && cls == CL_CHEAP) {
         if (kind == PROG_NODE_END) {
           if (!MEDIA || mode == 0) {
-            running = false;
+            if (!DEFER && ret_tail != 0) { next = ret_tail; ret_tail = 0; }  // end of the called section: go back
+            else running = false;
           } else if (mode == 1 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) {  // entry found at tmax: look for the exit
             t_entry = tmax;
             mode = 2; next = (uint32_t)(prog[med_at] >> 32); tmin = t_entry + 0.0001; tmax = RT_INF;
@@ -406,6 +419,9 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
           med = idx; med_at = i; ret_i = i + PROG_MEDIUM_UNITS; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
           mode = 1; next = count; tmin = -RT_INF; tmax = RT_INF;
           hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0);
+        } else if (kind == PROG_NODE_DEFER) {
+          if (DEFER) { deferred = true; next = i + 1; }
+          else { ret_tail = i + 1; next = count; }
         } else {
           next = i + prog_record_units(unit);  // a medium the query ignores, or filler
         }
@@ -541,6 +557,15 @@ RT_UNROLL
     if (running && next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
   }
   best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
+  return deferred;
+}
+
+// The whole walk (a DEFER unit is followed at once): world.hit as the reference runs it.
+template <bool MEDIA, class RaySrc>
+RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
+                       double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
+                       double* stale_uv) {
+  (void)walk_program<MEDIA, false>(S, prog, begin, active, rs, tm, tmin0, tmax0, best, use_media, rng, bounce, stale_uv);
 }
 
 RT_HD bool hit_any(const Hit& h) { return RTX_NODE_KIND(h.kind_idx) != RTX_NODE_NONE; }

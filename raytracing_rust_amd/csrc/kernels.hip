@@ -82,7 +82,7 @@ struct WfCounters {
   uint32_t gen_sample;  // sample offset of the first new path
   uint32_t gen_rem;     // its pixel rank within that sample
   uint32_t finished;    // set by k_wf_finish: the survivors have been run to their end
-  uint32_t _pad;
+  uint32_t n_defer;     // rays of this iteration that entered the deferred section
   unsigned long long next_path, total_paths;
 };
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
@@ -92,7 +92,7 @@ struct WfFrame {       // what a path index means: (sample offset, pixel rank); 
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
-  c->finished = 0; c->_pad = 0;
+  c->finished = 0; c->n_defer = 0;
   c->next_path = 0; c->total_paths = total;
 }
 
@@ -110,6 +110,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->next_path += g;
   c->n_in = survivors + g;
   c->n_out = 0;
+  c->n_defer = 0;
   stats[0] += g;  // only this single thread writes the path counter while a wavefront render runs
 }
 
@@ -148,47 +149,91 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
   }
 }
 
-// Traversal kernel: one closest-hit query per queued path (world.hit, camera.rs:179).  Persistent 1024-thread
-// workgroups, one per CU: each stages the whole hit program (nodes + boxes) in LDS once, then walks its share of
-// the queue; only primitive records and the ray/hit streams touch global memory.
-template <bool USE_LDS>
-__global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, const WfCounters* c,
-                                                      WfQueue q, WfHits h, unsigned long long* __restrict__ stats) {
+// Traversal kernels: one closest-hit query per queued path (world.hit, camera.rs:179).  Persistent 1024-thread
+// workgroups, one per CU: each stages its part of the program image in LDS once, then walks its share of the queue;
+// only the ray and hit streams (and the rare general primitive records) touch global memory.
+//
+// TAIL = false walks the world program.  When the program has a deferred section (Scene::tail_begin), a ray that
+// passes the section's root box is only noted: its queue index goes to the defer list (collected per wave in LDS,
+// flushed 64 at a time with one atomic).  TAIL = true then walks the section's own program for the rays of that
+// list, densely packed, starting from the hit found so far.  Together the two are the undivided walk.
+#define RT_DEFER_SLOTS 128u  // per wave: up to 63 waiting entries + 64 new ones
+template <bool USE_LDS, bool TAIL>
+__global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, WfCounters* c,
+                                                      WfQueue q, WfHits h, uint32_t* __restrict__ defer_list,
+                                                      unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
-  const uint32_t n = c->n_in;
+  const uint32_t n = TAIL ? c->n_defer : c->n_in;
   if (blockIdx.x * blockDim.x >= n) return;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t first_unit = TAIL ? S.tail_begin : 0u;
+  const uint32_t end_unit = (!TAIL && S.tail_begin) ? S.tail_begin : S.n_units;
   const uint64_t* prog = S.prog;
 #if defined(RT_PROF)
   for (uint32_t k = threadIdx.x; k < 16 * 30; k += blockDim.x) g_prof_lds[k] = 0;
   __syncthreads();
 #endif
   if (USE_LDS) {
-    const uint4* src = (const uint4*)S.prog;
+    const uint4* src = (const uint4*)(S.prog + first_unit);   // both bounds are even: 16-byte pieces
     uint4* dst = (uint4*)lds_prog;
-    for (uint32_t k = threadIdx.x; k < S.n_units / 2; k += blockDim.x) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < (end_unit - first_unit) / 2; k += blockDim.x) dst[k] = src[k];
     __syncthreads();
-    prog = lds_prog;
+    prog = lds_prog - first_unit;                              // unit indices stay those of the whole image
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
+  // per-wave collection buffer of deferred queue indices, behind the staged program
+  uint32_t* wave_defer = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + wave * RT_DEFER_SLOTS;
+  uint32_t n_wait = 0;  // entries waiting in wave_defer (the same in every lane)
+  const bool collect = !TAIL && S.tail_begin != 0;
+  if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
   // the trip count is the same for every lane of a wave: lanes past the end of the queue only vote
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-    const uint32_t idx = base + threadIdx.x;
-    const bool active = idx < n;
-    const uint32_t ld = active ? idx : 0;
+    const uint32_t k = base + threadIdx.x;
+    const bool active = k < n;
+    const uint32_t idx = TAIL ? defer_list[active ? k : 0] : (active ? k : 0);
     RayMem rs;
-    rs.f = q.f + ld; rs.cap = cap;
+    rs.f = q.f + idx; rs.cap = cap;
     const double tm = rs.f[6 * (size_t)cap];
     PathRng rng = rng_make(seed, 0, 0);
     uint32_t bounce = 0;
-    if (S.n_media) {
-      const uint32_t* u = q.u + ld;
+    if (!TAIL && S.n_media) {
+      const uint32_t* u = q.u + idx;
       rng = rng_make(seed, u[0], u[(size_t)cap]);
       bounce = u[2 * (size_t)cap] & 0xFFFFu;
     }
     Hit hit;
-    closest_hit<true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, S.n_media != 0, rng, bounce,
-                      h.uv + 2 * (size_t)ld);
-    if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
+    if (TAIL) {
+      // the section's program never holds media (the program compiler checks), so no RNG is needed here
+      const double t_so_far = h.t[idx];
+      walk_program<true, false>(S, prog, S.tail_begin, active, rs, tm, 0.001, t_so_far, hit, false, rng, bounce, h.uv + 2 * (size_t)idx);
+      if (active && hit_any(hit)) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
+    } else {
+      const bool deferred = walk_program<true, true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, S.n_media != 0, rng, bounce,
+                                                     h.uv + 2 * (size_t)idx);
+      if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
+      if (collect) {
+        const unsigned long long m = __ballot(active && deferred);
+        if (active && deferred) wave_defer[n_wait + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
+        n_wait += (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (n_wait >= 64u) {                                   // flush 64 entries with one atomic
+          uint32_t at = 0;
+          if (lane == 0) at = atomicAdd(&c->n_defer, 64u);
+          at = __shfl(at, 0);
+          defer_list[at + lane] = wave_defer[lane];
+          const uint32_t rest = lane < n_wait - 64u ? wave_defer[64u + lane] : 0u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (lane < n_wait - 64u) wave_defer[lane] = rest;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          n_wait -= 64u;
+        }
+      }
+    }
+  }
+  if (collect && n_wait) {
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&c->n_defer, n_wait);
+    at = __shfl(at, 0);
+    if (lane < n_wait) defer_list[at + lane] = wave_defer[lane];
   }
 #if defined(RT_PROF)
   __syncthreads();
@@ -420,14 +465,15 @@ struct rtx_context {
   int n_cus = 256;
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
-  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0;
-  uint64_t launches = 0, traverse_launches = 0;
+  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0;
+  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
   // wavefront workspace (allocated on first use, kept for the context's lifetime)
   uint32_t wf_cap = 0;
   WfQueue wf_q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   WfHits wf_hits = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* wf_defer = nullptr;  // queue indices of the rays that entered the deferred section
   WfCounters* wf_c = nullptr;
   WfCounters* wf_host = nullptr;  // pinned, two slots
   hipEvent_t wf_ev[2] = {nullptr, nullptr};
@@ -462,7 +508,8 @@ static void drain_events(rtx_context* ctx) {
     float ms = 0.f;
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       if (p.what == 0) { ctx->render_ms += ms; ctx->last_kernel_ms = ms; ctx->launches += 1; }
-      else { ctx->traverse_ms += ms; ctx->traverse_launches += 1; }
+      else if (p.what == 1) { ctx->traverse_ms += ms; ctx->traverse_launches += 1; }
+      else { ctx->tail_ms += ms; ctx->tail_launches += 1; }
     }
     ctx->free_events.push_back(p.e0); ctx->free_events.push_back(p.e1);
   }
@@ -608,7 +655,9 @@ static rtx_status wf_ensure(rtx_context* ctx) {
   HIP_TRY(ctx, A((void**)&ctx->wf_c, sizeof(WfCounters)));
   HIP_TRY(ctx, hipHostMalloc((void**)&ctx->wf_host, 2 * sizeof(WfCounters), hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[k], hipEventDisableTiming));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, A((void**)&ctx->wf_defer, (size_t)cap * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   ctx->wf_cap = cap;
   return RTX_OK;
 }
@@ -635,8 +684,13 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // a path of depth 0 is black (camera.rs:169-171): nothing to trace
   const unsigned long long total = cam->max_depth > 0 ? per_sample * (unsigned long long)(o->sample_end - o->sample_begin) : 0ull;
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
-  const size_t prog_bytes = (size_t)sc->dev.n_units * 8;
-  const bool use_lds = prog_bytes <= kLdsBudget;
+  // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
+  // defer buffers; the deferred section's own program
+  const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
+  const size_t main_bytes = (size_t)(tail_begin ? tail_begin : n_units) * 8;
+  const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
+  const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
+  const bool main_lds = main_bytes + defer_bytes <= kLdsBudget, tail_lds = tail_bytes <= kLdsBudget;
   const unsigned blocks256 = cap / 256;
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
   const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
@@ -652,11 +706,20 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin);
       TimedSpan sp;
       const bool timed = span_begin(ctx, stream, sp, 1);
-      if (use_lds)
-        hipLaunchKernelGGL(k_wf_traverse<true>, dim3(trav_blocks), dim3(RT_TRAV_THREADS), prog_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+      if (main_lds)
+        hipLaunchKernelGGL((k_wf_traverse<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), main_bytes + defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
       else
-        hipLaunchKernelGGL(k_wf_traverse<false>, dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->d_counters);
+        hipLaunchKernelGGL((k_wf_traverse<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
       if (timed) span_end(ctx, stream, sp);
+      if (sc->dev.tail_begin) {  // the deferred section for the rays that passed its root box
+        TimedSpan st;
+        const bool timed_tail = span_begin(ctx, stream, st, 2);
+        if (tail_lds)
+          hipLaunchKernelGGL((k_wf_traverse<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+        else
+          hipLaunchKernelGGL((k_wf_traverse<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+        if (timed_tail) span_end(ctx, stream, st);
+      }
       hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
       cur ^= 1;
     }
@@ -725,7 +788,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   static_cast<rtx_scene_desc&>(sc->dev) = *d;
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
-  sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev._pad1 = 0;
+  sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
@@ -869,6 +932,7 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   out->paths = c[0]; out->segments = c[1]; out->pdf_probes = c[2];
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
+  out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
   return RTX_OK;
 }
 
@@ -878,7 +942,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)));
-  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0;
+  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0;
   return RTX_OK;
 }
 
