@@ -248,9 +248,20 @@ struct CompiledProgram {
     DBox6 no_box;
     memset(&no_box, 0, sizeof(no_box));
     std::vector<Item> items;
+    // An ENTER/EXIT only sets the current context and rebuilds the local ray from the world ray, so it is redundant
+    // when another ENTER/EXIT follows immediately, and so is one right before the END of the world program.
+    std::vector<uint8_t> dropped((size_t)n + 1, 0);
     for (uint32_t i = b; i < e; ++i) {
       uint32_t kind = RTX_NODE_KIND(d.nodes[i].kind_idx);
       const uint32_t idx = RTX_NODE_IDX(d.nodes[i].kind_idx);
+      if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+        const uint32_t nk = i + 1 < e ? RTX_NODE_KIND(d.nodes[i + 1].kind_idx) : (uint32_t)RTX_NODE_NONE;
+        if (nk == RTX_NODE_ENTER || nk == RTX_NODE_EXIT || (i + 1 == e && sync)) {
+          dropped[i - b] = 1;
+          if (sync_before[i - b]) { sync_before[i - b] = 0; sync_before[i - b + 1] = 1; }
+          continue;
+        }
+      }
       if (kind == RTX_NODE_SPHERE && sphere_static[idx]) kind = PROG_NODE_SPHERE_S;
       else if (kind == RTX_NODE_QUAD && quad_aa[idx]) kind = PROG_NODE_QUAD_AA;
       else if (kind == RTX_NODE_MEDIUM && fuse_sphere_media && sphere_bounded(d, idx)) kind = PROG_NODE_MEDIUM_S;
@@ -298,6 +309,8 @@ struct CompiledProgram {
     }
     link[n] = at;
     if (sync_before[n]) at += 1;
+    for (uint32_t rel = n; rel-- > 0;)
+      if (dropped[rel]) link[rel] = link[rel + 1];   // a skip to a dropped node lands on what follows it
     const uint32_t end_at = at;
     units.resize((size_t)end_at + 1, nop());
     for (size_t k = 0; k < items.size(); ++k) {
