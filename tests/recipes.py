@@ -103,4 +103,22 @@ def empty_lists_and_media(g):
     return world, None, _rays_towards(rng, 3000, np.zeros(3), 70.0, 200.0)
 
 
-ALL = [flat_random_prims, bvh_mixed_leaves, nested_transforms, ties_edges_and_axis_parallel, empty_lists_and_media]
+def large_bvh_beyond_lds(g):
+    """Two BVHs over 3000 spheres and 1500 boxes: the compiled program (about 0.7 MB) does not fit the 160 KB of LDS, so
+    the traversal kernels read it from global memory; the transformed box BVH comes last and becomes the deferred
+    section."""
+    rng = np.random.default_rng(106)
+    mats = _materials(g)
+    spheres = g.list([g.sphere(rng.uniform(-200, 200, size=3), float(rng.uniform(2, 9)), mats[int(rng.integers(3))])
+                      for _ in range(3000)])
+    boxes = []
+    for _ in range(1500):
+        c = rng.uniform(-150, 150, size=3)
+        boxes.append(g.box(c, c + rng.uniform(3, 20, size=3), mats[0]))
+    world = g.list([g.bvh(spheres), g.quad((-300, -250, -300), (600, 0, 0), (0, 0, 600), mats[3]),
+                    g.translate(g.rotate_y(g.bvh(g.list(boxes)), 25.0), (30, 0, -40))])
+    return world, None, _rays_towards(rng, 8000, np.zeros(3), 220.0, 700.0)
+
+
+ALL = [flat_random_prims, bvh_mixed_leaves, nested_transforms, ties_edges_and_axis_parallel, empty_lists_and_media,
+       large_bvh_beyond_lds]
