@@ -182,3 +182,24 @@ def test_sphere_bounded_media_in_one_step_are_bit_identical(name, width):
     assert ca == cb
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     assert a.sum() > 0
+
+
+@pytest.mark.parametrize("name,width", [("final", 40)])
+def test_deferred_section_is_the_same_walk(name, width):
+    """The program compiler moves the last top-level box subtree into a program of its own behind a DEFER unit; walked
+    as a call it must give the render of the undivided program, bit for bit."""
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=width, spp=16, depth=12)
+    desc = rt.flatten(g, w, l)
+    opts = rt.render_opts(cam, sample_begin=0, sample_end=16, seed=6)
+    lib = H.hostsim_lib()
+    try:
+        lib.sim_set_defer_last_section(0)
+        a, ca = H.hostsim_render(desc, cam, opts)
+        lib.sim_set_defer_last_section(1)
+        b, cb = H.hostsim_render(desc, cam, opts)
+    finally:
+        lib.sim_set_defer_last_section(1)
+    assert ca == cb
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert a.sum() > 0
