@@ -73,13 +73,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # RTX_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo collectives on host copies, to rehearse the multi-rank
+    # control flow on a one-GPU box.  Not a measurement mode.
+    rehearsal = os.environ.get("RTX_BENCH_REHEARSAL") == "1"
+    device = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    coll = "cpu" if rehearsal else "cuda"
 
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(device)
     g = rt.Graph()
     world, lights, cam = rt.scenes.build("final", g, width=WIDTH, spp=SPP, depth=DEPTH)
     scene = rt.Scene.from_graph(ctx, g, world, lights)
@@ -109,14 +117,18 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
-    sharding.reduce_sum(accum, dist, dst=0)
-    if rank == 0:
+    if rehearsal and dist is not None:
         host = accum.cpu()
+        sharding.reduce_sum(host, dist, dst=0)
+    else:
+        sharding.reduce_sum(accum, dist, dst=0)
+        if rank == 0:
+            host = accum.cpu()
     fence()
     dt = time.perf_counter() - t0
     st = ctx.stats()
     if dist is not None:
-        t = torch.tensor([dt, float(st["segments"]), float(st["paths"])], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(st["segments"]), float(st["paths"])], dtype=torch.float64, device=coll)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
