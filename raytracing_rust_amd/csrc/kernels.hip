@@ -83,6 +83,8 @@ struct WfCounters {
   uint32_t gen_rem;     // its pixel rank within that sample
   uint32_t finished;    // set by k_wf_finish: the survivors have been run to their end
   uint32_t n_defer;     // rays of this iteration that entered the deferred section
+  uint32_t work_main, work_tail;  // next queue entry to hand out in the two traversal launches of this iteration
+  uint32_t work_shade, _pad;      // the same for the shading launch
   unsigned long long next_path, total_paths;
 };
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
@@ -92,7 +94,7 @@ struct WfFrame {       // what a path index means: (sample offset, pixel rank); 
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
-  c->finished = 0; c->n_defer = 0;
+  c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->_pad = 0;
   c->next_path = 0; c->total_paths = total;
 }
 
@@ -110,7 +112,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->next_path += g;
   c->n_in = survivors + g;
   c->n_out = 0;
-  c->n_defer = 0;
+  c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0;
   stats[0] += g;  // only this single thread writes the path counter while a wavefront render runs
 }
 
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 // flushed 64 at a time with one atomic).  TAIL = true then walks the section's own program for the rays of that
 // list, densely packed, starting from the hit found so far.  Together the two are the undivided walk.
 #define RT_DEFER_SLOTS 128u  // per wave: up to 63 waiting entries + 64 new ones
+#ifndef RT_WAVE_BATCH
+#define RT_WAVE_BATCH 128u   // most queue entries a wave takes per atomic (a multiple of 64)
+#endif
 template <bool USE_LDS, bool TAIL>
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, WfCounters* c,
                                                       WfQueue q, WfHits h, uint32_t* __restrict__ defer_list,
@@ -185,9 +190,22 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   uint32_t n_wait = 0;  // entries waiting in wave_defer (the same in every lane)
   const bool collect = !TAIL && S.tail_begin != 0;
   if (!TAIL && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
-  // the trip count is the same for every lane of a wave: lanes past the end of the queue only vote
-  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-    const uint32_t k = base + threadIdx.x;
+  // Work is handed out dynamically, RT_WAVE_BATCH queue entries per wave at a time (one atomic each): rays differ a
+  // lot in cost, and a static split leaves CUs idle at the end of the launch.  The trip count is the same for every
+  // lane of a wave: lanes past the end of the queue only vote.
+  uint32_t* work = TAIL ? &c->work_tail : &c->work_main;
+  const uint32_t n_waves = gridDim.x * (blockDim.x / 64u);
+  uint32_t seen = 0;  // the counter as this wave last saw it: batches shrink as the queue runs out (guided scheduling)
+  for (;;) {
+    uint32_t batch = ((n - seen) / (2u * n_waves)) & ~63u;
+    batch = batch < 64u ? 64u : (batch > RT_WAVE_BATCH ? RT_WAVE_BATCH : batch);
+    uint32_t wbase = 0;
+    if (lane == 0) wbase = atomicAdd(work, batch);
+    wbase = __shfl(wbase, 0);
+    if (wbase >= n) break;
+    seen = wbase;
+  for (uint32_t pass = 0; pass < batch && wbase + pass < n; pass += 64u) {
+    const uint32_t k = wbase + pass + lane;
     const bool active = k < n;
     const uint32_t idx = TAIL ? defer_list[active ? k : 0] : (active ? k : 0);
     RayMem rs;
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       }
     }
   }
+  }
   if (collect && n_wait) {
     uint32_t at = 0;
     if (lane == 0) at = atomicAdd(&c->n_defer, n_wait);
@@ -254,9 +273,14 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t n = c->n_in;
   uint32_t probes = 0;
-  __shared__ uint32_t s_count[4], s_base;
-  // grid-stride over the queue: the trip count is the same for every thread of a workgroup
-  for (uint32_t first = blockIdx.x * blockDim.x; first < n; first += gridDim.x * blockDim.x) {
+  __shared__ uint32_t s_count[4], s_base, s_first;
+  // the queue is handed out dynamically, one workgroup's worth at a time: the trip count is the same for every thread
+  // of a workgroup, and no workgroup is left with a long static share at the end of the launch
+  for (;;) {
+  if (threadIdx.x == 0) s_first = atomicAdd(&c->work_shade, blockDim.x);
+  __syncthreads();
+  const uint32_t first = s_first;
+  if (first >= n) break;
   const uint32_t idx = first + threadIdx.x;
   bool alive = false;
   PathState ps;
