@@ -94,6 +94,20 @@ int rtxh_scene_final(rtxh_session* s, int width, int spp, int depth, uint64_t se
 rtx_status rtxh_camera_render(rtxh_session* s, rtx_context* ctx, rtx_camera_desc* cam, int world, int lights,
                               uint64_t seed, const char* output_filename, uint8_t* rgb_out, double* seconds_out);
 
+/* Camera::render in batches of rows of the sqrt_spp x sqrt_spp stratification, with progress reports and a
+ * checkpoint of the accumulator after every batch.  No counterpart in the reference, which shows an indicatif
+ * progress bar (camera.rs:277-285) and saves only at the end (camera.rs:322): a 5000-spp render cannot be resumed
+ * there.  If checkpoint_path names a checkpoint of the same scene, camera and seed, the render continues after the
+ * rows it holds; the file is rewritten atomically after every batch.  progress (may be NULL) is called after every
+ * batch; a non-zero return stops the render (the checkpoint then holds the rows done).  rows_done_out (may be NULL)
+ * receives the rows rendered so far; the PNG is written only when all rows are done; rgb_out (may be NULL) receives
+ * the image of the rows done, scaled as the finished image would be. */
+typedef int (*rtxh_progress_fn)(int rows_done, int rows_total, double seconds, void* user);
+rtx_status rtxh_camera_render_progressive(rtxh_session* s, rtx_context* ctx, rtx_camera_desc* cam, int world, int lights,
+                                          uint64_t seed, int rows_per_batch, const char* checkpoint_path,
+                                          rtxh_progress_fn progress, void* user, const char* output_filename,
+                                          uint8_t* rgb_out, int* rows_done_out);
+
 /* RgbImage::save (camera.rs:322): 8-bit RGB PNG through zlib. */
 rtx_status rtxh_write_png(const char* path, const uint8_t* rgb, int width, int height);
 

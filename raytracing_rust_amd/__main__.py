@@ -25,6 +25,8 @@ def main(argv=None):
     ap.add_argument("--depth", type=int)
     ap.add_argument("--out")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=scenes.PATH_SEED)
+    ap.add_argument("--checkpoint", help="render in batches and keep the accumulator in this file; resumes if it exists")
+    ap.add_argument("--rows-per-batch", type=int, default=5, help="rows of the stratification per batch (with --checkpoint)")
     args = ap.parse_args(argv)
     if args.scene is None:                                                # main.rs:39-44
         print("usage: python -m raytracing_rust_amd [cornell|final|quick|smoke]", file=sys.stderr)
@@ -37,8 +39,21 @@ def main(argv=None):
     ctx = Context(0)
     out = (args.out or OUTPUT[args.scene]).encode()
     secs = C.c_double(0.0)
-    st = _capi.lib.rtxh_camera_render(g.session, ctx.handle, C.byref(cam), world, -1 if lights is None else lights,
-                                      args.seed, out, None, C.byref(secs))
+    if args.checkpoint:
+        import time
+        t0 = time.perf_counter()
+
+        def report(rows, total, seconds, _user):
+            print(f"  rows {rows}/{total}  {seconds:7.1f} s", file=sys.stderr)
+            return 0
+        cb = _capi.PROGRESS_FN(report)
+        st = _capi.lib.rtxh_camera_render_progressive(g.session, ctx.handle, C.byref(cam), world,
+                                                      -1 if lights is None else lights, args.seed, args.rows_per_batch,
+                                                      args.checkpoint.encode(), cb, None, out, None, None)
+        secs.value = time.perf_counter() - t0
+    else:
+        st = _capi.lib.rtxh_camera_render(g.session, ctx.handle, C.byref(cam), world, -1 if lights is None else lights,
+                                          args.seed, out, None, C.byref(secs))
     if st != _capi.RTX_OK:
         msg = _capi.lib.rtx_last_error(ctx.handle) or _capi.lib.rtxh_last_error(g.session)
         raise RtxError(st, msg.decode() if msg else "")

@@ -109,6 +109,8 @@ class Stats(C.Structure):
                 ("tail_launches", u64)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p)
+
 # Every symbol the two headers declare: name -> (restype, argtypes).
 P = C.c_void_p
 PD = C.POINTER(f64)
@@ -159,6 +161,8 @@ SYMBOLS = {
     "rtxh_scene_cornell_smoke": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
     "rtxh_scene_final": (C.c_int, [P, C.c_int, C.c_int, C.c_int, u64, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
     "rtxh_camera_render": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_char_p, C.POINTER(u8), PD]),
+    "rtxh_camera_render_progressive": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_int, C.c_char_p,
+                                                 PROGRESS_FN, P, C.c_char_p, C.POINTER(u8), C.POINTER(C.c_int)]),
     "rtxh_write_png": (C.c_int, [C.c_char_p, C.POINTER(u8), C.c_int, C.c_int]),
 }
 

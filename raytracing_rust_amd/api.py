@@ -239,3 +239,21 @@ class Camera:
             raise _r.RtxError(st, msg.decode() if msg else "")
         self.last_render_seconds = secs.value
         return rgb
+
+    def render_progressive(self, world, lights=None, rows_per_batch=1, checkpoint=None, progress=None, save=True):
+        """The same render in batches of rows of the stratification, with a checkpoint of the accumulator after every
+        batch (resumed if `checkpoint` already holds one of this render) and `progress(rows_done, rows_total, seconds)`
+        after every batch; a true return value stops the render.  Returns (rgb, rows_done)."""
+        cam = self.desc()
+        rgb = np.empty((cam.image_height, cam.image_width, 3), dtype=np.uint8)
+        done = C.c_int(0)
+        cb = _capi.PROGRESS_FN((lambda r, n, s, u: 1 if progress(r, n, s) else 0) if progress else (lambda r, n, s, u: 0))
+        fn = self.output_filename.encode() if (save and self.output_filename) else None
+        st = _capi.lib.rtxh_camera_render_progressive(
+            session().session, context().handle, C.byref(cam), world.h, -1 if lights is None else lights.h, self.seed,
+            int(rows_per_batch), str(checkpoint).encode() if checkpoint else None, cb, None, fn,
+            rgb.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(done))
+        if st != _capi.RTX_OK:
+            msg = _capi.lib.rtx_last_error(context().handle) or _capi.lib.rtxh_last_error(session().session)
+            raise _r.RtxError(st, msg.decode() if msg else "")
+        return rgb, done.value

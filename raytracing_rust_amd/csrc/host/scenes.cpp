@@ -267,4 +267,118 @@ rtx_status rtxh_camera_render(rtxh_session* s, rtx_context* ctx, rtx_camera_desc
   return st;
 }
 
+// ---- progressive rendering with checkpoints -------------------------------------------------------------------
+namespace {
+struct CkptHeader {
+  char magic[8];                       // "RTXCKPT1"
+  int32_t width, height, sqrt_spp, samples_per_pixel, max_depth, next_row;
+  uint64_t seed, fingerprint;
+};
+uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+// A cheap identity of scene + camera: a checkpoint of another render must not be resumed.
+uint64_t fingerprint(const rtx_scene_desc& d, const rtx_camera_desc& c) {
+  uint64_t h = 1469598103934665603ull;
+  h = fnv1a(h, d.nodes, sizeof(rtx_node) * d.n_nodes);
+  h = fnv1a(h, d.boxes, sizeof(rtx_aabb) * d.n_boxes);
+  h = fnv1a(h, d.spheres, sizeof(rtx_sphere) * d.n_spheres);
+  h = fnv1a(h, d.quads, sizeof(rtx_quad) * d.n_quads);
+  h = fnv1a(h, d.materials, sizeof(rtx_material) * d.n_materials);
+  h = fnv1a(h, d.textures, sizeof(rtx_texture) * d.n_textures);
+  h = fnv1a(h, &c, sizeof(c));
+  return h;
+}
+bool save_checkpoint(const char* path, const CkptHeader& hd, const std::vector<double>& accum) {
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  bool ok = fwrite(&hd, sizeof(hd), 1, f) == 1 && fwrite(accum.data(), sizeof(double), accum.size(), f) == accum.size();
+  ok = (fclose(f) == 0) && ok;
+  if (ok) ok = rename(tmp.c_str(), path) == 0;   // the previous checkpoint stays valid until the new one is complete
+  if (!ok) remove(tmp.c_str());
+  return ok;
+}
+bool load_checkpoint(const char* path, const CkptHeader& want, CkptHeader& got, std::vector<double>& accum) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  bool ok = fread(&got, sizeof(got), 1, f) == 1 && memcmp(got.magic, want.magic, 8) == 0 && got.width == want.width &&
+            got.height == want.height && got.sqrt_spp == want.sqrt_spp && got.samples_per_pixel == want.samples_per_pixel &&
+            got.max_depth == want.max_depth && got.seed == want.seed && got.fingerprint == want.fingerprint &&
+            got.next_row >= 0 && got.next_row <= want.sqrt_spp;
+  std::vector<double> tmp(accum.size());
+  ok = ok && fread(tmp.data(), sizeof(double), tmp.size(), f) == tmp.size();
+  fclose(f);
+  if (ok) accum.swap(tmp);
+  return ok;
+}
+}  // namespace
+
+rtx_status rtxh_camera_render_progressive(rtxh_session* s, rtx_context* ctx, rtx_camera_desc* cam, int world, int lights,
+                                          uint64_t seed, int rows_per_batch, const char* checkpoint_path,
+                                          rtxh_progress_fn progress, void* user, const char* output_filename,
+                                          uint8_t* rgb_out, int* rows_done_out) {
+  if (!s || !ctx || !cam || rows_per_batch < 1) return RTX_ERR_INVALID;
+  rtx_status st = rtx_camera_initialize(cam);
+  if (st != RTX_OK) return st;
+  rtx_scene_desc desc;
+  st = rtxh_flatten(s, world, lights, &desc);
+  if (st != RTX_OK) return st;
+  rtx_scene* scene = nullptr;
+  st = rtx_scene_create(ctx, &desc, &scene);
+  if (st != RTX_OK) return st;
+  const size_t npix = (size_t)cam->image_width * (size_t)cam->image_height;
+  std::vector<double> accum(npix * 3, 0.0);
+  CkptHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  memcpy(hd.magic, "RTXCKPT1", 8);
+  hd.width = cam->image_width; hd.height = cam->image_height; hd.sqrt_spp = cam->sqrt_spp;
+  hd.samples_per_pixel = cam->samples_per_pixel; hd.max_depth = cam->max_depth; hd.seed = seed;
+  hd.fingerprint = fingerprint(desc, *cam);
+  int row = 0;
+  if (checkpoint_path) {
+    CkptHeader got;
+    if (load_checkpoint(checkpoint_path, hd, got, accum)) row = got.next_row;   // resume where the last run stopped
+  }
+  const int rows = cam->sqrt_spp;
+  auto t0 = std::chrono::steady_clock::now();
+  bool stopped = false;
+  while (row < rows && st == RTX_OK && !stopped) {
+    const int end = row + rows_per_batch < rows ? row + rows_per_batch : rows;
+    rtx_render_opts o;
+    memset(&o, 0, sizeof(o));
+    o.sample_begin = row * rows; o.sample_end = end * rows;
+    o.x0 = 0; o.y0 = 0; o.x1 = cam->image_width; o.y1 = cam->image_height;
+    o.seed = seed; o.use_lights = 1; o.pipeline = RTX_PIPELINE_DEFAULT;
+    st = rtx_render(scene, cam, &o, accum.data());
+    if (st != RTX_OK) break;
+    row = end;
+    if (checkpoint_path) {
+      hd.next_row = row;
+      if (!save_checkpoint(checkpoint_path, hd, accum)) { st = RTX_ERR_IO; break; }
+    }
+    if (progress) {
+      const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      stopped = progress(row, rows, secs, user) != 0;
+    }
+  }
+  if (rows_done_out) *rows_done_out = row;
+  std::vector<uint8_t> rgb(npix * 3);
+  // an unfinished image is resolved with the samples it has, scaled as the finished one would be (color.rs:16-52)
+  const int spp_so_far = row == rows ? cam->samples_per_pixel
+                                     : (int)((long long)cam->samples_per_pixel * row / rows > 0 ? (long long)cam->samples_per_pixel * row / rows : 1);
+  if (st == RTX_OK) st = rtx_resolve_rgb8(ctx, accum.data(), cam->image_width, cam->image_height, spp_so_far, rgb.data());
+  rtx_scene_destroy(scene);
+  if (st != RTX_OK) return st;
+  if (rgb_out) memcpy(rgb_out, rgb.data(), rgb.size());
+  if (output_filename && row == rows) {
+    st = rtxh_write_png(output_filename, rgb.data(), cam->image_width, cam->image_height);
+    if (st == RTX_OK) fprintf(stderr, "image saved as %s\n", output_filename);
+    else fprintf(stderr, "error while saving image %s\n", output_filename);
+  }
+  return st;
+}
+
 }  // extern "C"

@@ -1,0 +1,69 @@
+"""GPU tier: rendering in batches with a checkpoint after every batch, stopping and resuming (the reference saves only
+at the end, camera.rs:322).  Uses the reference-shaped Python classes, like scene code of the reference."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracing_rust_amd.api as rt
+
+
+def cornell():
+    """cornell_box.rs:35-105 in small: five walls, a light, two boxes."""
+    rt.reset_session()
+    red, white, green = (rt.Lambertian.new(rt.Color(*c)) for c in ((.65, .05, .05), (.73, .73, .73), (.12, .45, .15)))
+    light = rt.DiffuseLight.new_color(rt.Color(15, 15, 15))
+    world = rt.HittableList.new()
+    world.add(rt.Quad.new(rt.Point3(555, 0, 0), rt.Vec3(0, 555, 0), rt.Vec3(0, 0, 555), green))
+    world.add(rt.Quad.new(rt.Point3(0, 0, 0), rt.Vec3(0, 555, 0), rt.Vec3(0, 0, 555), red))
+    lamp = rt.Quad.new(rt.Point3(343, 554, 332), rt.Vec3(-130, 0, 0), rt.Vec3(0, 0, -105), light)
+    world.add(lamp)
+    world.add(rt.Quad.new(rt.Point3(0, 0, 0), rt.Vec3(555, 0, 0), rt.Vec3(0, 0, 555), white))
+    world.add(rt.Quad.new(rt.Point3(555, 555, 555), rt.Vec3(-555, 0, 0), rt.Vec3(0, 0, -555), white))
+    world.add(rt.Quad.new(rt.Point3(0, 0, 555), rt.Vec3(555, 0, 0), rt.Vec3(0, 555, 0), white))
+    box1 = rt.Translate.new(rt.RotateY.new(rt.box_new(rt.Point3(0, 0, 0), rt.Point3(165, 330, 165), white), 15.0), rt.Vec3(265, 0, 295))
+    world.add(box1)
+    lights = rt.HittableList.new()
+    lights.add(lamp)
+    cam = rt.Camera.new()
+    cam.image_width, cam.samples_per_pixel, cam.max_depth = 64, 36, 12
+    cam.background = rt.Color(0, 0, 0)
+    cam.vfov, cam.lookfrom, cam.lookat = 40.0, rt.Point3(278, 278, -800), rt.Point3(278, 278, 0)
+    return world, lights, cam
+
+
+@pytest.mark.gpu
+def test_stop_and_resume_gives_the_uninterrupted_image(tmp_path):
+    world, lights, cam = cornell()
+    ckpt = tmp_path / "render.ckpt"
+    seen = []
+    whole, done = cam.render_progressive(world, lights, rows_per_batch=2, progress=lambda r, n, s: seen.append((r, n)) and False,
+                                         save=False)
+    assert done == 6 and seen == [(2, 6), (4, 6), (6, 6)]
+    # stop after two batches, then call again with the same checkpoint
+    part, done = cam.render_progressive(world, lights, rows_per_batch=2, checkpoint=ckpt, progress=lambda r, n, s: r >= 4, save=False)
+    assert done == 4 and os.path.exists(ckpt)
+    assert os.path.getsize(ckpt) == 48 + 64 * 64 * 3 * 8
+    resumed_rows = []
+    cam.output_filename = str(tmp_path / "resumed.png")
+    full, done = cam.render_progressive(world, lights, rows_per_batch=2, checkpoint=ckpt,
+                                        progress=lambda r, n, s: resumed_rows.append(r) and False)
+    assert done == 6 and resumed_rows == [6]                      # only the missing batch was rendered
+    assert os.path.exists(cam.output_filename)
+    # same paths (RNG addressed by pixel and sample); f64 atomics may add in another order: at most one 8-bit step
+    diff = np.abs(full.astype(int) - whole.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+    # the partial image is the same picture with more noise, not a darker one
+    assert abs(part.mean() - whole.mean()) < 0.15 * whole.mean()
+
+
+@pytest.mark.gpu
+def test_checkpoint_of_another_render_is_ignored(tmp_path):
+    world, lights, cam = cornell()
+    ckpt = tmp_path / "render.ckpt"
+    cam.render_progressive(world, lights, rows_per_batch=3, checkpoint=ckpt, progress=lambda r, n, s: True, save=False)
+    cam.seed += 1                                                  # another render: must start from row 0
+    rows = []
+    _, done = cam.render_progressive(world, lights, rows_per_batch=3, checkpoint=ckpt, progress=lambda r, n, s: rows.append(r) and False,
+                                     save=False)
+    assert done == 6 and rows == [3, 6]
