@@ -88,6 +88,12 @@ int rtxh_scene_cornell_smoke(rtxh_session* s, int width, int spp, int depth, int
 int rtxh_scene_final(rtxh_session* s, int width, int spp, int depth, uint64_t seed, int earth_tex, int* lights_out,
                      rtx_camera_desc* cam);
 
+/* Synthetic stress scene (not in the reference): n_prims random spheres and quads of mixed materials in one BvhNode,
+ * up to 64 emitting quads as lights, camera at (0,0,-2500), 16:9.  The benchmark configuration is 1 M primitives at
+ * 3840x2160, 4096 spp, depth 50, seed 0x5EED0005.  lights_out receives -1 when no primitive emits. */
+int rtxh_scene_stress(rtxh_session* s, int n_prims, uint64_t seed, int width, int spp, int depth, int* lights_out,
+                      rtx_camera_desc* cam);
+
 /* Camera::render (camera.rs:271-328): initialise the camera, flatten, render every sample of every pixel on the GPU,
  * resolve to RGB8 and write cam's image as PNG (output_filename may be NULL to skip the file).  rgb_out may be NULL.
  * seconds_out (may be NULL) receives the wall time of the render call alone. */

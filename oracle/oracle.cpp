@@ -1302,4 +1302,48 @@ int orc_scene_final(void* s, int width, int spp, int depth, uint64_t seed, int e
   return world;
 }
 
+// Synthetic stress scene (not in the reference; the same recipe as the product's host layer, stated independently):
+// primitive i is a sphere for even i (centre U[-1000,1000)^3, radius U[1,5)) and a quad for odd i (corner
+// U[-1000,1000)^3, edges U[-5,5)^3); one draw picks the material: < 0.70 Lambertian of a random colour, < 0.85 Metal
+// (albedo U[0.5,1)^3, fuzz U[0,0.5)), < 0.95 Dielectric 1.5, else an emitter of radiance 10 if it is a quad and grey
+// Lambertian if not; the first 64 emitting quads are the lights.  Everything sits in one BvhNode.
+int orc_scene_stress(void* s, int n_prims, uint64_t seed, int width, int spp, int depth, int* lights_out, CameraDesc* cam) {
+  if (n_prims < 1) return -1;
+  HostRng rng(seed);
+  int all = orc_list_new(s), lights = orc_list_new(s), n_lights = 0;
+  for (int i = 0; i < n_prims; ++i) {
+    const bool quad = (i & 1) != 0;
+    const double pick = rng.next_double();
+    int mat;
+    bool emitter = false;
+    if (pick < 0.70) { double r = rng.next_double(), g = rng.next_double(), b = rng.next_double(); mat = lambert_color(s, r, g, b); }
+    else if (pick < 0.85) { double r = rng.range(0.5, 1.0), g = rng.range(0.5, 1.0), b = rng.range(0.5, 1.0); mat = orc_mat_metal(s, r, g, b, rng.range(0.0, 0.5)); }
+    else if (pick < 0.95) mat = orc_mat_dielectric(s, 1.5);
+    else if (quad) { mat = orc_mat_diffuse_light(s, orc_tex_solid(s, 10, 10, 10)); emitter = true; }
+    else mat = lambert_color(s, 0.5, 0.5, 0.5);
+    int obj;
+    if (!quad) {
+      double c[3] = {rng.range(-1000, 1000), rng.range(-1000, 1000), rng.range(-1000, 1000)};
+      obj = orc_sphere(s, c, rng.range(1.0, 5.0), mat);
+    } else {
+      double q[3] = {rng.range(-1000, 1000), rng.range(-1000, 1000), rng.range(-1000, 1000)};
+      double u[3] = {rng.range(-5, 5), rng.range(-5, 5), rng.range(-5, 5)};
+      double v[3] = {rng.range(-5, 5), rng.range(-5, 5), rng.range(-5, 5)};
+      obj = orc_quad(s, q, u, v, mat);
+      if (emitter && n_lights < 64) { orc_list_add(s, lights, obj); ++n_lights; }
+    }
+    if (obj < 0) return -1;
+    orc_list_add(s, all, obj);
+  }
+  int world = orc_list_new(s);
+  orc_list_add(s, world, orc_bvh(s, all));
+  camera_defaults(*cam);
+  cam->aspect_ratio = 16.0 / 9.0; cam->image_width = width; cam->samples_per_pixel = spp; cam->max_depth = depth;
+  d3(cam->background, 0, 0, 0);
+  cam->vfov = 40.0; d3(cam->lookfrom, 0, 0, -2500); d3(cam->lookat, 0, 0, 0); d3(cam->vup, 0, 1, 0);
+  cam->defocus_angle = 0.0;
+  *lights_out = n_lights ? lights : -1;
+  return world;
+}
+
 }  // extern "C"

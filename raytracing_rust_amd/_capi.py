@@ -160,6 +160,7 @@ SYMBOLS = {
     "rtxh_scene_cornell": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
     "rtxh_scene_cornell_smoke": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
     "rtxh_scene_final": (C.c_int, [P, C.c_int, C.c_int, C.c_int, u64, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
+    "rtxh_scene_stress": (C.c_int, [P, C.c_int, u64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(CameraDesc)]),
     "rtxh_camera_render": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_char_p, C.POINTER(u8), PD]),
     "rtxh_camera_render_progressive": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_int, C.c_char_p,
                                                  PROGRESS_FN, P, C.c_char_p, C.POINTER(u8), C.POINTER(C.c_int)]),

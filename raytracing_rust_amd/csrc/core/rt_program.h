@@ -172,6 +172,7 @@ struct CompiledProgram {
       }
     }
     if (d.world_end <= d.world_begin) return false;
+    if (last == d.world_begin) return false;   // a world of one subtree: deferring it would leave the first pass empty
     const uint32_t kind = RTX_NODE_KIND(d.nodes[last].kind_idx);
     uint32_t end = d.world_end;
     if (kind == RTX_NODE_BOX) {

@@ -156,6 +156,52 @@ int rtxh_scene_final(rtxh_session* s, int width, int spp, int depth, uint64_t se
   return world;
 }
 
+// Synthetic stress scene (not in the reference): n_prims primitives, even ones spheres (centre U[-1000,1000)^3, radius
+// U[1,5)), odd ones quads (corner U[-1000,1000)^3, edges U[-5,5)^3), in ONE BvhNode.  Materials by one draw per
+// primitive: 70 % Lambertian of a random colour, 15 % Metal (albedo U[0.5,1)^3, fuzz U[0,0.5)), 10 % Dielectric 1.5,
+// 5 % emitters of radiance 10 when the primitive is a quad (grey Lambertian otherwise); the first 64 emitting quads
+// form the lights list.  Camera at (0,0,-2500) looking at the origin, vfov 40, 16:9, black background.
+int rtxh_scene_stress(rtxh_session* s, int n_prims, uint64_t seed, int width, int spp, int depth, int* lights_out,
+                      rtx_camera_desc* cam) {
+  if (n_prims < 1) return -1;
+  HostRng rng(seed);
+  int all = rtxh_list_new(s), lights = rtxh_list_new(s), n_lights = 0;
+  for (int i = 0; i < n_prims; ++i) {
+    const bool quad = (i & 1) != 0;
+    const double pick = rng.next_double();
+    int mat;
+    bool emitter = false;
+    if (pick < 0.70) { double r = rng.next_double(), g = rng.next_double(), b = rng.next_double(); mat = lambertian_color(s, r, g, b); }
+    else if (pick < 0.85) { double r = rng.range(0.5, 1.0), g = rng.range(0.5, 1.0), b = rng.range(0.5, 1.0); mat = rtxh_mat_metal(s, r, g, b, rng.range(0.0, 0.5)); }
+    else if (pick < 0.95) mat = rtxh_mat_dielectric(s, 1.5);
+    else if (quad) { mat = diffuse_light_color(s, 10, 10, 10); emitter = true; }
+    else mat = lambertian_color(s, 0.5, 0.5, 0.5);
+    int obj;
+    if (!quad) {
+      double c[3] = {rng.range(-1000, 1000), rng.range(-1000, 1000), rng.range(-1000, 1000)};
+      obj = rtxh_sphere(s, c, rng.range(1.0, 5.0), mat);
+    } else {
+      double q[3] = {rng.range(-1000, 1000), rng.range(-1000, 1000), rng.range(-1000, 1000)};
+      double u[3] = {rng.range(-5, 5), rng.range(-5, 5), rng.range(-5, 5)};
+      double v[3] = {rng.range(-5, 5), rng.range(-5, 5), rng.range(-5, 5)};
+      obj = rtxh_quad(s, q, u, v, mat);
+      if (emitter && n_lights < 64) { rtxh_list_add(s, lights, obj); ++n_lights; }
+    }
+    if (obj < 0) return -1;
+    rtxh_list_add(s, all, obj);
+  }
+  int world = rtxh_list_new(s);
+  rtxh_list_add(s, world, rtxh_bvh(s, all));
+  camera_defaults(cam);
+  cam->aspect_ratio = 16.0 / 9.0; cam->image_width = width; cam->samples_per_pixel = spp; cam->max_depth = depth;
+  set3(cam->background, 0, 0, 0);
+  cam->vfov = 40.0;
+  set3(cam->lookfrom, 0, 0, -2500); set3(cam->lookat, 0, 0, 0); set3(cam->vup, 0, 1, 0);
+  cam->defocus_angle = 0.0;
+  *lights_out = n_lights ? lights : -1;
+  return world;
+}
+
 // Camera::initialize, camera.rs:89-129.
 rtx_status rtx_camera_initialize(rtx_camera_desc* c) {
   if (!c || c->image_width < 1 || !(c->aspect_ratio > 0.0) || c->samples_per_pixel < 1) return RTX_ERR_INVALID;

@@ -22,7 +22,11 @@ ENTRY_POINTS = {
     "final": ("final", 800, 5000, 75),
     "quick": ("final", 400, 100, 20),
     "smoke": ("cornell_smoke", 600, 1000, 50),
+    # not a reference entry point: 1 M random spheres and quads in one BVH, the synthetic stress configuration
+    "stress": ("stress", 3840, 4096, 50),
 }
+STRESS_SEED = 0x5EED0005
+STRESS_PRIMS = 1_000_000
 
 
 def load_ppm(path):
@@ -39,7 +43,8 @@ def earth_pixels():
     return load_ppm(os.path.join(ASSETS, "earthmap.ppm"))
 
 
-def build(name, graph, width=None, spp=None, depth=None, scene_seed=SCENE_SEED, prefix="rtxh_", lib=None):
+def build(name, graph, width=None, spp=None, depth=None, scene_seed=SCENE_SEED, prefix="rtxh_", lib=None,
+          n_prims=STRESS_PRIMS):
     """Build one of the named scenes into `graph`.  Returns (world, lights, cam)."""
     fn_name, w0, s0, d0 = ENTRY_POINTS[name]
     width, spp, depth = width or w0, spp or s0, depth or d0
@@ -52,6 +57,11 @@ def build(name, graph, width=None, spp=None, depth=None, scene_seed=SCENE_SEED, 
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(_capi.CameraDesc)]
         earth = graph.image(earth_pixels())
         world = fn(graph.session, width, spp, depth, scene_seed, earth, C.byref(lights), C.byref(cam))
+    elif fn_name == "stress":
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(_capi.CameraDesc)]
+        seed = STRESS_SEED if scene_seed == SCENE_SEED else scene_seed
+        world = fn(graph.session, int(n_prims), seed, width, spp, depth, C.byref(lights), C.byref(cam))
     else:
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(_capi.CameraDesc)]

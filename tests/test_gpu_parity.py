@@ -28,6 +28,25 @@ def test_first_hit_aov_bit_exact_named_scenes(gpu_ctx, name, width):
     scene.close()
 
 
+def test_first_hit_aov_bit_exact_stress_scene(gpu_ctx):
+    """The synthetic stress configuration at 200 000 primitives (a 13 MB hit program, walked from global memory):
+    first hits bit-exact against the oracle's recursive BVH, and both pipelines trace the same paths through it."""
+    go, wo, lo, gp, wp, lp, cam = _pair("stress", width=480, spp=4, depth=12, n_prims=200000)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    rays = rt.pixel_center_rays(cam, time=0.5)
+    ref = H.oracle_first_hit(go, wo, rays)
+    H.assert_aov_equal(ref, scene.first_hit(rays), "stress")
+    assert np.isfinite(ref["t"]).sum() > 20000
+    out = {}
+    for pipe in (_capi.PIPELINE_FUSED, _capi.PIPELINE_WAVEFRONT):
+        gpu_ctx.reset_stats()
+        out[pipe] = (scene.render(cam, rt.render_opts(cam, seed=9, pipeline=pipe)), gpu_ctx.stats())
+    (a, sa), (b, sb) = out[_capi.PIPELINE_FUSED], out[_capi.PIPELINE_WAVEFRONT]
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 @pytest.mark.parametrize("recipe", recipes.ALL, ids=lambda r: r.__name__)
 def test_first_hit_aov_bit_exact_recipes(gpu_ctx, recipe):
     """Random and edge-case graphs: nested transforms, BVHs of mixed leaves, ties, axis-parallel rays, empty lists."""

@@ -20,6 +20,21 @@ def test_named_scenes_bit_exact(name, width):
         H.assert_aov_equal(H.oracle_first_hit(go, wo, rays), H.hostsim_first_hit(rt.flatten(gp, wp, lp), rays), name)
 
 
+def test_stress_scene_bit_exact():
+    """The synthetic stress configuration at a reduced primitive count: the two scene builders draw the same scene
+    (same camera, same counts), and the hit program finds the oracle's hits in a BVH of 30 000 mixed leaves."""
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam_o = scenes.build("stress", go, width=256, n_prims=30000, prefix="orc_", lib=H.oracle_lib())
+    wp, lp, cam = scenes.build("stress", gp, width=256, n_prims=30000)
+    assert bytes(cam_o) == bytes(cam) and cam.image_height == 144
+    d = rt.flatten(gp, wp, lp)
+    assert d.n_spheres == 15000 and d.n_quads == 15000 and d.n_boxes == 32767 and d.n_lights == 64
+    rays = rt.pixel_center_rays(cam, time=0.5)
+    a = H.oracle_first_hit(go, wo, rays)
+    H.assert_aov_equal(a, H.hostsim_first_hit(d, rays), "stress")
+    assert np.isfinite(a["t"]).sum() > 2000
+
+
 @pytest.mark.parametrize("recipe", recipes.ALL, ids=lambda r: r.__name__)
 def test_recipes_bit_exact(recipe):
     go, gp = H.oracle_graph(), rt.Graph()
