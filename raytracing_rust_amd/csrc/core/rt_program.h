@@ -35,6 +35,7 @@ struct CompiledProgram {
   std::vector<uint8_t> sphere_static, quad_aa;
   uint32_t world_begin = 0;
   uint32_t n_box6 = 0;
+  uint32_t n_general_media = 0;    // MEDIUM units emitted (media whose boundary needs a program of its own)
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
@@ -353,6 +354,7 @@ struct CompiledProgram {
         u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
         memcpy(u + 3, &rec, sizeof(rec));
       } else if (it.kind == RTX_NODE_MEDIUM) {
+        ++n_general_media;
         u[0] = (uint64_t)d.nodes[it.node].kind_idx | ((uint64_t)media[it.idx].b_begin << 32);
         u[1] = bits(d.media[it.idx].neg_inv_density);
         u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);

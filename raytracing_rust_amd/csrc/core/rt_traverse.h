@@ -346,13 +346,16 @@ struct RayMem {       // structure-of-arrays queue: f[k*cap], k = 0..5
 // Lanes therefore share each expensive instruction stream instead of serialising sphere, quad and medium code in
 // every trip.  The order of steps within one ray is untouched, so results do not depend on the schedule.
 //
-// MEDIA = false skips ConstantMedium nodes (the deterministic first-hit AOV).  With MEDIA, a medium node runs its
+// MEDIA = MEDIA_NONE skips ConstantMedium nodes (the deterministic first-hit AOV).  MEDIA_SPHERES is for programs whose
+// media are all of the one-step sphere-bounded kind (MEDIUM_S units; the scene says whether that holds): the code
+// and registers of the general case drop out.  With MEDIA_ALL, a medium node runs its
 // boundary program twice through this same loop (constant_medium.rs:47-57: entry over the whole line, exit after
 // entry + 1e-4) by saving the outer query in a few registers instead of calling itself; boundaries never contain
 // media (checked when the scene is created).  The free-path draw of a medium uses the medium's table index as RNG
-// counter, so it does not depend on how paths are scheduled.  stale_uv (2 doubles, may be null) receives the
-// (u,v) the reference's record still holds when a medium whose phase texture reads them scatters
-// (constant_medium.rs:81-87 leaves u,v untouched).
+// counter, so it does not depend on how paths are scheduled.  When a medium whose phase texture reads (u,v) scatters,
+// the reference's record still holds the (u,v) of the closest surface hit found before it (constant_medium.rs:81-87
+// leaves u,v untouched): stale_uv (2 doubles, may be null) then receives that hit (its t, and kind_idx | ctx << 32 as a
+// bit pattern), from which resolve_hit computes the two values.
 //
 // Deferred section.  The program compiler may move the last top-level box subtree of the world (with its transform)
 // into a program of its own and leave a DEFER unit behind the subtree's root box (rt_program.h).  With DEFER = false
@@ -360,7 +363,8 @@ struct RayMem {       // structure-of-arrays queue: f[k*cap], k = 0..5
 // With DEFER = true the walk notes that the ray passed the root box, skips the section and returns true; the caller
 // runs the section later (same ray, tmax0 = the t found so far), which is the same walk cut in two because the
 // section is the last thing the world program visits.
-template <bool MEDIA, bool DEFER, class RaySrc>
+enum { MEDIA_NONE = 0, MEDIA_SPHERES = 1, MEDIA_ALL = 2 };
+template <int MEDIA, bool DEFER, class RaySrc>
 RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                         double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                         double* stale_uv) {
@@ -392,7 +396,7 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
     else if (kind == RTX_NODE_SPHERE) cls = CL_SPHERE;
     else if (kind == RTX_NODE_QUAD) cls = CL_QUAD;
     else if (kind == PROG_NODE_SYNC) cls = CL_SYNC;
-    else if (MEDIA && kind == PROG_NODE_END && mode == 2 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) cls = CL_MEDIUM_EVAL;
+    else if (MEDIA == MEDIA_ALL && kind == PROG_NODE_END && mode == 2 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) cls = CL_MEDIUM_EVAL;
     else if (MEDIA && kind == PROG_NODE_MEDIUM_S && use_media) cls = CL_MEDIUM_S;
     uint32_t next = i;  // unit to stand on after this trip
     if (RT_WAVE_ANY(running && cls == CL_CHEAP)) {
@@ -400,7 +404,7 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
       // 2. other cheap units
       if (running && cls == CL_CHEAP) {
         if (kind == PROG_NODE_END) {
-          if (!MEDIA || mode == 0) {
+          if (MEDIA != MEDIA_ALL || mode == 0) {
             if (!DEFER && ret_tail != 0) { next = ret_tail; ret_tail = 0; }  // end of the called section: go back
             else running = false;
           } else if (mode == 1 && RTX_NODE_KIND(hit_kind) != RTX_NODE_NONE) {  // entry found at tmax: look for the exit
@@ -414,7 +418,7 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
           cur = idx;
           lr = lray_from_ops(prog + i + 1, count, rs.origin(), rs.dir());
           next = i + 1 + PROG_XFORM_OP_UNITS * count;
-        } else if (MEDIA && kind == RTX_NODE_MEDIUM && use_media) {
+        } else if (MEDIA == MEDIA_ALL && kind == RTX_NODE_MEDIUM && use_media) {
           // save the enclosing query, run the boundary program from this context over the whole line
           med = idx; med_at = i; ret_i = i + PROG_MEDIUM_UNITS; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
           mode = 1; next = count; tmin = -RT_INF; tmax = RT_INF;
@@ -513,7 +517,7 @@ RT_UNROLL
         // the exit at tmax (entry in t_entry), the enclosing query waits in out_*.  MEDIUM_S: the boundary is one static
         // sphere, so both crossings (entry over the whole line, exit after entry + 1e-4, constant_medium.rs:47-57) are
         // computed here with the same sphere routine and the enclosing query is simply the current one.
-        const bool eval = running && cls == CL_MEDIUM_EVAL, direct = running && cls == CL_MEDIUM_S;
+        const bool eval = MEDIA == MEDIA_ALL && running && cls == CL_MEDIUM_EVAL, direct = running && cls == CL_MEDIUM_S;
         if (eval || direct) {
           const uint32_t at = direct ? i : med_at;
           double t_in = t_entry, t_out = tmax;
@@ -536,13 +540,10 @@ RT_UNROLL
               double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
               double hit_distance = neg_inv_density * log(xi);
               if (!(hit_distance > inside)) {
-                if (needs_uv && stale_uv) {
-                  stale_uv[0] = 0.0; stale_uv[1] = 0.0;
-                  if (RTX_NODE_KIND(out_kind) == RTX_NODE_SPHERE || RTX_NODE_KIND(out_kind) == RTX_NODE_QUAD) {
-                    Ray w;
-                    w.o = rs.origin(); w.d = rs.dir(); w.tm = tm;
-                    hit_uv(S, w, out_kind, out_ctx, out_tmax, stale_uv[0], stale_uv[1]);
-                  }
+                if (needs_uv && stale_uv) {  // the surface hit this scattering replaces: resolve_hit turns it into (u,v)
+                  const uint64_t id = (uint64_t)out_kind | ((uint64_t)out_ctx << 32);
+                  stale_uv[0] = out_tmax;
+                  memcpy(&stale_uv[1], &id, 8);
                 }
                 out_tmax = t1 + hit_distance / ray_length;
                 out_kind = RTX_NODE_MAKE(RTX_NODE_MEDIUM, med); out_ctx = ret_cur;
@@ -565,7 +566,7 @@ template <bool MEDIA, class RaySrc>
 RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                        double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                        double* stale_uv) {
-  (void)walk_program<MEDIA, false>(S, prog, begin, active, rs, tm, tmin0, tmax0, best, use_media, rng, bounce, stale_uv);
+  (void)walk_program<MEDIA ? MEDIA_ALL : MEDIA_NONE, false>(S, prog, begin, active, rs, tm, tmin0, tmax0, best, use_media, rng, bounce, stale_uv);
 }
 
 RT_HD bool hit_any(const Hit& h) { return RTX_NODE_KIND(h.kind_idx) != RTX_NODE_NONE; }
@@ -605,7 +606,12 @@ RT_HD void resolve_hit(const Scene& S, const Ray& wray, const Hit& h, bool want_
     sf.n = v3(1.0, 0.0, 0.0);
     sf.front = true;
     sf.mat = S.media[idx].mat; sf.prim_id = 0xFFFFFFFEu;
-    if (want_uv && stale_uv) { sf.u = stale_uv[0]; sf.v = stale_uv[1]; }
+    if (want_uv && stale_uv) {  // (u,v) of the surface hit the walk had found before this medium scattered, if any
+      uint64_t id;
+      memcpy(&id, &stale_uv[1], 8);
+      const uint32_t k = RTX_NODE_KIND((uint32_t)id);
+      if (k == RTX_NODE_SPHERE || k == RTX_NODE_QUAD) hit_uv(S, wray, (uint32_t)id, (uint32_t)(id >> 32), stale_uv[0], sf.u, sf.v);
+    }
   }
   if (h.ctx != 0) ctx_to_world(S, h.ctx, sf.p, sf.n);
 }

@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 #ifndef RT_WAVE_BATCH
 #define RT_WAVE_BATCH 128u   // most queue entries a wave takes per atomic (a multiple of 64)
 #endif
-template <bool USE_LDS, bool TAIL>
+//
+// MM (MEDIA_NONE / MEDIA_SPHERES / MEDIA_ALL) is what the world program needs for its media: a program without
+// general MEDIUM units runs the variant without the boundary-program machinery, which saves it registers.
+template <bool USE_LDS, bool TAIL, int MM>
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, WfCounters* c,
                                                       WfQueue q, WfHits h, uint32_t* __restrict__ defer_list,
                                                       unsigned long long* __restrict__ stats) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     const double tm = rs.f[6 * (size_t)cap];
     PathRng rng = rng_make(seed, 0, 0);
     uint32_t bounce = 0;
-    if (!TAIL && S.n_media) {
+    if (!TAIL && MM != MEDIA_NONE) {
       const uint32_t* u = q.u + idx;
       rng = rng_make(seed, u[0], u[(size_t)cap]);
       bounce = u[2 * (size_t)cap] & 0xFFFFu;
@@ -222,10 +225,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     if (TAIL) {
       // the section's program never holds media (the program compiler checks), so no RNG is needed here
       const double t_so_far = h.t[idx];
-      walk_program<true, false>(S, prog, S.tail_begin, active, rs, tm, 0.001, t_so_far, hit, false, rng, bounce, h.uv + 2 * (size_t)idx);
+      walk_program<MEDIA_NONE, false>(S, prog, S.tail_begin, active, rs, tm, 0.001, t_so_far, hit, false, rng, bounce, h.uv + 2 * (size_t)idx);
       if (active && hit_any(hit)) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
     } else {
-      const bool deferred = walk_program<true, true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, S.n_media != 0, rng, bounce,
+      const bool deferred = walk_program<MM, true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, rng, bounce,
                                                      h.uv + 2 * (size_t)idx);
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
       if (collect) {
@@ -507,6 +510,7 @@ struct rtx_context {
 struct rtx_scene {
   rtx_context* ctx = nullptr;
   Scene dev;  // device pointers
+  uint32_t n_general_media = 0;  // media of the world program whose boundary is a program of its own
   std::vector<void*> allocs;
 };
 
@@ -680,8 +684,10 @@ static rtx_status wf_ensure(rtx_context* ctx) {
   HIP_TRY(ctx, hipHostMalloc((void**)&ctx->wf_host, 2 * sizeof(WfCounters), hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[k], hipEventDisableTiming));
   HIP_TRY(ctx, A((void**)&ctx->wf_defer, (size_t)cap * sizeof(uint32_t)));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   ctx->wf_cap = cap;
   return RTX_OK;
 }
@@ -715,6 +721,10 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
   const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
   const bool main_lds = main_bytes + defer_bytes <= kLdsBudget, tail_lds = tail_bytes <= kLdsBudget;
+  // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
+  const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
+  auto k_main = main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
+                         : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
   const unsigned blocks256 = cap / 256;
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
   const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
@@ -730,18 +740,15 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin);
       TimedSpan sp;
       const bool timed = span_begin(ctx, stream, sp, 1);
-      if (main_lds)
-        hipLaunchKernelGGL((k_wf_traverse<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), main_bytes + defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
-      else
-        hipLaunchKernelGGL((k_wf_traverse<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+      hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
       if (timed) span_end(ctx, stream, sp);
       if (sc->dev.tail_begin) {  // the deferred section for the rays that passed its root box
         TimedSpan st;
         const bool timed_tail = span_begin(ctx, stream, st, 2);
         if (tail_lds)
-          hipLaunchKernelGGL((k_wf_traverse<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+          hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
         else
-          hipLaunchKernelGGL((k_wf_traverse<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+          hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
         if (timed_tail) span_end(ctx, stream, st);
       }
       hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
@@ -813,6 +820,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
+  sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
