@@ -269,10 +269,13 @@ RT_HD bool sphere_s_hit_t(const DSphere& s, const V3& o, const V3& d, double tmi
 // product with an exact zero of normal / w drops out of the reference's dot products without changing their value,
 // so t is bit-identical and the interior test decides identically (alpha, beta can differ in the sign of a zero).
 RT_HD bool aaquad_hit_t(const DAAQuad& q, const V3& o, const V3& d, double tmin, double tmax, double& t) {
-  double ok, dk, oa, da, ob, db;
-  if (q.axis == 0) { ok = o.x; dk = d.x; oa = o.y; da = d.y; ob = o.z; db = d.z; }
-  else if (q.axis == 1) { ok = o.y; dk = d.y; oa = o.z; da = d.z; ob = o.x; db = d.x; }
-  else { ok = o.z; dk = d.z; oa = o.x; da = d.x; ob = o.y; db = d.y; }
+  // components picked by value selects (the six values are read first: a select between their addresses would keep
+  // the ray in addressable scratch memory on the GPU)
+  const double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+  const bool k0 = q.axis == 0, k1 = q.axis == 1;
+  const double ok = k0 ? ox : (k1 ? oy : oz), dk = k0 ? dx : (k1 ? dy : dz);
+  const double oa = k0 ? oy : (k1 ? oz : ox), da = k0 ? dy : (k1 ? dz : dx);
+  const double ob = k0 ? oz : (k1 ? ox : oy), db = k0 ? dz : (k1 ? dx : dy);
   double denom = q.nk * dk;
   if (fabs(denom) < 1e-8) return false;
   double tt = (q.d - q.nk * ok) / denom;
