@@ -27,12 +27,11 @@ WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
 # throughput 24 + ids 12 + hit 16 = 108 B) and its survivor record (80 + 12 = 92 B) or pixel atomics (24 B): ~300 B.
 TRAVERSE_BYTES = 84
 BOUNCE_BYTES = 300
-# HBM-side traffic of the world-program traversal kernel (k_wf_traverse<true,false>) per segment, from rocprofv3 PMC
-# passes over this command with --rows 10 --steps 1 (1.0698e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE
-# 98.93e9 B doubled (the gfx950 half-count correction; calibrated for 16-byte loads, these are 8-byte ones, so an
-# upper bound) + WRITE_SIZE 103.1e9 B.  It exceeds the algorithmic bytes because of register-spill stores and because
-# each workgroup re-stages the program image per launch.
-TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 98.93e9 + 103.1e9) / 1.0698e9
+# HBM-side traffic of the world-program traversal kernel per segment, from rocprofv3 PMC passes over this command with
+# --rows 10 --steps 1 --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 54.83e9 B doubled (the
+# gfx950 half-count correction; it is calibrated for 16-byte loads and these are 8-byte ones, so an upper bound; the
+# ray reads alone are 72.7e9 B) + WRITE_SIZE 18.55e9 B (hit records: 17.1e9 B).
+TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 54.83e9 + 18.55e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
 
 
@@ -159,7 +158,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if fused else seg_per_launch * TRAVERSE_PMC_TRAFFIC_PER_SEGMENT,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r1_pmc_summary.txt",
-                         "kernel": "k_render_fused" if fused else "k_wf_traverse<true,false>", "kernel_ms": kernel_ms,
+                         "kernel": "k_render_fused" if fused else "k_wf_traverse<true,false,1>", "kernel_ms": kernel_ms,
                          "launches": n_launch, "segments_per_launch": seg_per_launch,
                          "algorithmic_bytes_per_segment": seg_bytes,
                          "algorithmic_bytes_per_launch": seg_per_launch * seg_bytes,
