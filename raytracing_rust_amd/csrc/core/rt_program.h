@@ -36,6 +36,7 @@ struct CompiledProgram {
   uint32_t world_begin = 0;
   uint32_t n_box6 = 0;
   uint32_t n_general_media = 0;    // MEDIUM units emitted (media whose boundary needs a program of its own)
+  bool guard_box6 = true;          // a widened box test in front of every BOX6 (tests switch it off to compare)
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
@@ -219,12 +220,12 @@ struct CompiledProgram {
     return RTX_NODE_KIND(ki) == RTX_NODE_SPHERE && sphere_static[RTX_NODE_IDX(ki)];
   }
 
-  static uint32_t item_units(const rtx_scene_desc& d, const Item& it) {
+  uint32_t item_units(const rtx_scene_desc& d, const Item& it) const {
     switch (it.kind) {
       case RTX_NODE_BOX: return PROG_BOX_UNITS;
       case PROG_NODE_SPHERE_S: return 1u + PROG_SPHERE_S_UNITS * it.count;
       case PROG_NODE_QUAD_AA: return 1u + PROG_QUAD_AA_UNITS * it.count;
-      case PROG_NODE_BOX6: return PROG_BOX6_UNITS;
+      case PROG_NODE_BOX6: return (guard_box6 ? PROG_BOX_UNITS : 0u) + PROG_BOX6_UNITS;
       case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * d.xforms[it.idx].n_ops;
       case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
       case PROG_NODE_MEDIUM_S: return PROG_MEDIUM_S_UNITS;
@@ -336,6 +337,22 @@ struct CompiledProgram {
         u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
         for (uint32_t s = 0; s < it.count; ++s) memcpy(u + 1 + PROG_QUAD_AA_UNITS * s, &daaquads[it.idx + s], sizeof(DAAQuad));
       } else if (it.kind == PROG_NODE_BOX6) {
+        if (guard_box6) {
+          // Guard: a box test of the box's own bounds, widened, in front of its six faces.  A ray that misses the widened
+          // bounds cannot hit a face (the faces lie on the unwidened surface and the margin exceeds the rounding of both
+          // tests by many orders of magnitude), so the guard only saves the six quad tests and never changes a result.
+          const DBox6& bx = it.box6;
+          const double lo[3] = {std::min(bx.x0, bx.x1), std::min(bx.y0, bx.y1), std::min(bx.z0, bx.z1)};
+          const double hi[3] = {std::max(bx.x0, bx.x1), std::max(bx.y0, bx.y1), std::max(bx.z0, bx.z1)};
+          rtx_aabb g;
+          for (int a = 0; a < 3; ++a) {
+            const double pad = 1e-6 * (1.0 + std::max(fabs(lo[a]), fabs(hi[a])));
+            g.lo[a] = lo[a] - pad; g.hi[a] = hi[a] + pad;
+          }
+          u[0] = (uint64_t)RTX_NODE_MAKE(RTX_NODE_BOX, 0) | ((uint64_t)(p + PROG_BOX_UNITS + PROG_BOX6_UNITS) << 32);
+          memcpy(u + 1, &g, sizeof(g));
+          u += PROG_BOX_UNITS;
+        }
         u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)6u << 32);
         memcpy(u + 1, &it.box6, sizeof(DBox6));
       } else if (it.kind == RTX_NODE_ENTER || it.kind == RTX_NODE_EXIT) {

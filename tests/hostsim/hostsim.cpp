@@ -17,14 +17,14 @@ static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 
 using namespace rt;
 
-static bool g_fuse_sphere_media = true, g_defer_last_section = true;  // compile options under test
+static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true;  // compile options under test
 
 extern "C" {
 
 int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                   uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -48,13 +48,14 @@ int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, doub
 }
 
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
+void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }
 
 // counters: paths, segments, pdf_probes
 int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
                uint64_t* counters, int nthreads) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   if (nthreads < 1) nthreads = 1;
@@ -92,7 +93,7 @@ int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx
 // bytes, len receives the per-ray lengths.
 void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, uint32_t cap, uint8_t* seq, uint32_t* len) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene S = prog.host_view(*desc);
   for (size_t i = 0; i < n; ++i) {
     const double* r = rays + 7 * i;
@@ -111,7 +112,7 @@ void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, u
 // Histogram of unit kinds of the compiled program (16 counters) + total units in counts[16].
 void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   for (int k = 0; k < 17; ++k) counts[k] = 0;
   for (size_t i = 0; i < prog.units.size();) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)prog.units[i]);
@@ -136,7 +137,7 @@ void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x3
 void sim_philox10(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32_r<10>(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* uvp, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -146,14 +147,14 @@ void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* u
 }
 void sim_lights_pdf(const rtx_scene_desc* desc, const double* origin, const double* dirs, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); }
 }
 void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_t seed, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {

@@ -203,3 +203,34 @@ def test_deferred_section_is_the_same_walk(name, width):
     assert ca == cb
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     assert a.sum() > 0
+
+
+@pytest.mark.parametrize("name,width", [("final", 40), ("cornell", 32)])
+def test_box6_guards_never_change_a_result(name, width):
+    """The program compiler puts a widened box test in front of every six-face box record; it may only save work.  The
+    render with and without the guards must be the same bit for bit, and so must the first hits of rays that graze
+    the boxes (pixel-centre rays and rays along box edges)."""
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=width, spp=16, depth=12)
+    desc = rt.flatten(g, w, l)
+    opts = rt.render_opts(cam, sample_begin=0, sample_end=16, seed=6)
+    rays = rt.pixel_center_rays(cam, time=0.25)
+    # rays that run exactly along faces and edges of the boxes: origins on box corners, axis-parallel directions
+    q = np.array([[desc.quads[i].q[k] for k in range(3)] for i in range(min(desc.n_quads, 600))])
+    axes = np.eye(3)[np.arange(len(q)) % 3] * np.where(np.arange(len(q)) % 2, 1.0, -1.0)[:, None]
+    graze = np.concatenate([q - 50.0 * axes, axes, np.full((len(q), 1), 0.25)], axis=1)
+    rays = np.concatenate([rays, graze])
+    lib = H.hostsim_lib()
+    try:
+        lib.sim_set_guard_box6(0)
+        a, ca = H.hostsim_render(desc, cam, opts)
+        ha = H.hostsim_first_hit(desc, rays)
+        lib.sim_set_guard_box6(1)
+        b, cb = H.hostsim_render(desc, cam, opts)
+        hb = H.hostsim_first_hit(desc, rays)
+    finally:
+        lib.sim_set_guard_box6(1)
+    assert ca == cb
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    H.assert_aov_equal(ha, hb, name)
+    assert np.isfinite(ha["t"][-len(graze):]).sum() > len(graze) // 2

@@ -145,7 +145,7 @@ def main():
     report("secondary", secs, "random")
 
 
-if __name__ == "__main__" and not any(a in sys.argv for a in ("--refill", "--sort", "--phased", "--threshold")):
+if __name__ == "__main__" and not any(a in sys.argv for a in ("--refill", "--sort", "--phased", "--threshold", "--exits", "--ideal")):
     main()
 
 
@@ -371,3 +371,101 @@ if __name__ == "__main__" and "--threshold" in sys.argv:
         for th in (64, 48, 32, 16, 8, 1):
             c, tr = simulate_threshold_refill(seqs, threshold=th)
             print(f"   refill at >= {th:2d} idle lanes: {c:8.0f}   refills {tr.get('refill', 0):.1f} box trips {tr.get(BOX, 0):.0f}")
+
+
+# ---- phased policy with early exits (costs: tools/prof_trips.py of the current kernels)
+MEASURED2 = {BOX: 796, ENTER: 2008, EXIT: 2008, MEDIUM: 2008, NOP: 2008, END: 2008, 13: 2008, 33: 3256, 34: 3113, 35: 3750, 36: 3853,
+             37: 6882, 38: 1904, 39: 4885, 41: 6882}
+
+
+class PolPhasedExit:
+    """Phased policy; the box phase ends early once at most `t_box` lanes stand on a box while at least `u_leaf` lanes
+    wait on one leaf class; the leaf phase runs classes largest first and, while boxes are pending, skips classes with
+    fewer than `u_min` lanes."""
+    def __init__(self, t_box=0, u_leaf=65, u_min=0):
+        self.phase = "box"; self.t_box = t_box; self.u_leaf = u_leaf; self.u_min = u_min
+
+    def __call__(self, counts, nlive):
+        cand = {c: n for c, n in counts.items() if c != 38}
+        if not cand:
+            return 38
+        nb = {c: n for c, n in cand.items() if c != BOX}
+        if self.phase == "box":
+            n_box = cand.get(BOX, 0)
+            big = max(nb.values()) if nb else 0
+            if n_box > 0 and not (n_box <= self.t_box and big >= self.u_leaf):
+                return BOX
+            self.phase = "leaf"
+        if not nb:
+            self.phase = "box"
+            return BOX
+        for c in (END, ENTER, EXIT, MEDIUM, NOP, 13):
+            if c in nb:
+                return c
+        c = max(nb, key=lambda c: nb[c])
+        if BOX in cand and nb[c] < self.u_min:
+            self.phase = "box"
+            return BOX
+        return c
+
+
+if __name__ == "__main__" and "--exits" in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    COST.update(MEASURED2); globals()['TRIP_OVERHEAD'] = 0
+    for label, seqs in (("primary", trace(desc, tiles)), ("secondary", trace(desc, sec))):
+        # the world-program kernel sees the sequence up to the DEFER unit and what follows the section's END
+        main_part, tail_part = [], []
+        for s in seqs[:64 * 150]:
+            at = np.nonzero(s == 13)[0]
+            if len(at):
+                e = at[0] + 1 + int(np.nonzero(s[at[0] + 1:] == END)[0][0])
+                main_part.append(np.concatenate([s[:at[0] + 1], s[e + 1:]])); tail_part.append(s[at[0] + 1:e + 1])
+            else:
+                main_part.append(s)
+        for part, ss in (("world program", main_part), ("deferred section", tail_part)):
+            waves = [ss[i:i + 64] for i in range(0, len(ss) - 63, 64)]
+            if not waves:
+                continue
+            print(f"{label} / {part}: {len(waves)} waves")
+            for name, mk in [("phased (current)", lambda: PolPhasedExit())] + \
+                    [(f"box exit t<={t} u>={u}", (lambda t=t, u=u: PolPhasedExit(t, u))) for t in (4, 8, 16) for u in (16, 32)] + \
+                    [(f"leaf min {m}", (lambda m=m: PolPhasedExit(0, 65, m))) for m in (4, 8, 16)] + \
+                    [(f"exit t<=8 u>=32 + leaf min 8", lambda: PolPhasedExit(8, 32, 8))]:
+                res = [simulate(wv, mk()) for wv in waves]
+                trips = {}
+                for r in res:
+                    for c, n in r[1].items():
+                        trips[c] = trips.get(c, 0) + n / len(res)
+                print(f"   {name:30s} {np.mean([r[0] for r in res]):8.0f} cycles/64 rays   box trips {trips.get(BOX, 0):5.1f} BOX6 {trips.get(39, 0):4.1f} SPHERE_S {trips.get(33, 0):4.1f}")
+
+
+if __name__ == "__main__" and "--ideal" in sys.argv:
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=128, spp=100, depth=75)
+    desc = rt.flatten(g, w, l)
+    rays = rt.pixel_center_rays(cam, time=0.3).reshape(cam.image_height, cam.image_width, 7)
+    tiles = rays.reshape(cam.image_height // 8, 8, cam.image_width // 8, 8, 7).transpose(0, 2, 1, 3, 4).reshape(-1, 7)
+    hit = H.hostsim_first_hit(desc, tiles)
+    ok = np.isfinite(hit["t"])
+    rng = np.random.default_rng(7)
+    p = tiles[:, 0:3] + tiles[:, 3:6] * np.where(ok, hit["t"], 1.0)[:, None]
+    d = hit["normal"] + rng.normal(size=(len(tiles), 3)) * 0.8
+    sec = np.concatenate([p, d, tiles[:, 6:7]], axis=1)[ok]
+    seqs = trace(desc, sec)[:64 * 150]
+    tot = {}
+    for s in seqs:
+        for c in s:
+            tot[int(c)] = tot.get(int(c), 0) + 1
+    n = len(seqs)
+    print("steps per ray by kind:", {k: round(v / n, 2) for k, v in sorted(tot.items())})
+    print("perfectly packed waves: %.0f cycles per 64 rays" % (sum(MEASURED2[k] * v for k, v in tot.items()) / n))
