@@ -195,6 +195,8 @@ typedef struct rtx_stats { /* totals since context creation */
   uint64_t traverse_launches;
   double tail_ms;        /* device time of the deferred-section traversal launches, when the program has one */
   uint64_t tail_launches;
+  double head_ms;        /* device time of the head-section traversal launches, when the program has one */
+  uint64_t head_launches;
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;

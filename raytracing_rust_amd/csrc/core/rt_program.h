@@ -35,6 +35,8 @@ struct CompiledProgram {
   std::vector<uint8_t> sphere_static, quad_aa;
   uint32_t world_begin = 0;
   uint32_t n_box6 = 0;
+  uint32_t head_end = 0;           // SYNC unit behind the world's first top-level item when that is a large box subtree
+  bool split_head = true;          // look for such a head section (tests switch it off to compare)
   uint32_t n_general_media = 0;    // MEDIUM units emitted (media whose boundary needs a program of its own)
   bool guard_box6 = true;          // a widened box test in front of every BOX6 (tests switch it off to compare)
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
@@ -81,6 +83,7 @@ struct CompiledProgram {
     } else {
       world_begin = emit_range(d, d.world_begin, d.world_end, true);
     }
+    if (split_head) find_head(d);
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
   }
@@ -93,6 +96,7 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
+    S.head_end = head_end; S._pad_scene = 0;
     return S;
   }
 
@@ -200,6 +204,24 @@ struct CompiledProgram {
       if (kk == RTX_NODE_BOX) ++boxes;
     }
     return boxes >= 32;
+  }
+
+  // Head section: the world program starts (in the world context) with a box subtree of at least 32 boxes that holds
+  // no medium; it ends at the SYNC unit its root box skips to.
+  void find_head(const rtx_scene_desc& d) {
+    head_end = 0;
+    if (d.world_end <= d.world_begin || RTX_NODE_KIND(d.nodes[d.world_begin].kind_idx) != RTX_NODE_BOX) return;
+    const uint64_t root = units[world_begin];
+    if (RTX_NODE_KIND((uint32_t)root) != RTX_NODE_BOX) return;
+    const uint32_t end = (uint32_t)(root >> 32);
+    if (end <= world_begin || end >= units.size() || RTX_NODE_KIND((uint32_t)units[end]) != PROG_NODE_SYNC) return;
+    uint32_t boxes = 0;
+    for (uint32_t i = world_begin; i < end; i += prog_record_units(units[i])) {
+      const uint32_t k = RTX_NODE_KIND((uint32_t)units[i]);
+      if (k == RTX_NODE_MEDIUM || k == PROG_NODE_MEDIUM_S || k == PROG_NODE_DEFER || k == PROG_NODE_END || k == PROG_NODE_SYNC) return;
+      if (k == RTX_NODE_BOX) ++boxes;
+    }
+    if (boxes >= 32) head_end = end;
   }
 
   // ENTER record of transform context `ctx` (header + op chain).

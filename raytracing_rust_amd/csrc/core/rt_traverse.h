@@ -55,6 +55,9 @@ struct Scene : rtx_scene_desc {
   uint32_t n_units;
   uint32_t tail_begin;  // first unit of the deferred section's program (0 = the world program has none); the units
                         // before it are all a walk with DEFER = true can reach
+  uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
+                        // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
+  uint32_t _pad_scene;
 };
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
@@ -104,9 +107,11 @@ RT_HD uint32_t prog_record_units(uint64_t unit) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WAVE_ANY(p) (__ballot(p) != 0ull)
 #define RT_WAVE_COUNT(p) ((int)__popcll(__ballot(p)))
+#define RT_WAVE_LANES 64
 #else
 #define RT_WAVE_ANY(p) (p)
 #define RT_WAVE_COUNT(p) ((p) ? 1 : 0)
+#define RT_WAVE_LANES 1
 #endif
 
 struct LRay {     // ray in the current transform context + per-axis reciprocals (aabb.rs:146)
@@ -370,7 +375,7 @@ enum { MEDIA_NONE = 0, MEDIA_SPHERES = 1, MEDIA_ALL = 2 };
 template <int MEDIA, bool DEFER, class RaySrc>
 RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                         double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
-                        double* stale_uv) {
+                        double* stale_uv, uint32_t kind0 = RTX_NODE_MAKE(RTX_NODE_NONE, 0), uint32_t ctx0 = 0) {
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8, CL_MEDIUM_S = 9 };
   uint32_t cur = 0;
   uint32_t ret_tail = 0;  // DEFER = false: where to continue after the deferred program's END (0 = not inside it)
@@ -380,7 +385,7 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
   if (active) lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
   uint32_t i = begin;
   double tmin = tmin0, tmax = tmax0;
-  uint32_t hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0;
+  uint32_t hit_kind = kind0, hit_ctx = ctx0;  // the hit an earlier part of the same walk found at tmax0, if any
   // state of the enclosing query while a medium boundary program runs
   int mode = 0;  // 0: world program, 1: boundary entry query, 2: boundary exit query
   uint32_t ret_i = 0, ret_cur = 0, out_kind = 0, out_ctx = 0, med = 0, med_at = 0;
@@ -573,6 +578,160 @@ RT_HD void closest_hit(const Scene& S, const uint64_t* prog, uint32_t begin, boo
 }
 
 RT_HD bool hit_any(const Hit& h) { return RTX_NODE_KIND(h.kind_idx) != RTX_NODE_NONE; }
+
+// A section of the program walked as a STREAM of rays: a lane whose ray has left the section takes the next ray of
+// the queue at once instead of idling until the other 63 lanes of its wave are done.  For sections that are one
+// box subtree (a BVH and its leaves; no media) lanes differ widely in the number of boxes they visit, and in the
+// per-ray form above most box steps run with a quarter of the lanes.  The walk of each single ray is unchanged: same
+// units in the same order with the same running tmax, so results are bit-identical to walk_program over the section.
+//
+// The section starts at unit `begin` (world context) and ends where a lane meets an END or SYNC unit.  `feed` hands
+// out rays and takes results (wave-collective on the GPU):
+//   bool more()                         the queue may still hold rays (uniform over the wave)
+//   bool take(bool want, uint32_t& id)  lanes with `want` receive the next rays; false = none for this lane now
+//   Ray source: ray(id) (origin()/dir() as for walk_program), time(id)
+//   void start(id, tmax, kind, ctx)     the closest hit known before the section (tmax = RT_INF, kind NONE if none)
+//   void commit(id, tmax, kind, ctx)    the closest hit after the section
+// Scheduling: box steps run in a tight loop while the lanes on boxes outweigh the lanes waiting on a leaf
+// (RT_STREAM_LEAF_BIAS box lanes count like one waiting lane: a leaf test costs several box tests) and fewer than
+// RT_STREAM_REFILL lanes are out of work; leaves are served largest class first.
+#ifndef RT_STREAM_REFILL
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_STREAM_REFILL 16
+#else
+#define RT_STREAM_REFILL 1
+#endif
+#endif
+#ifndef RT_STREAM_LEAF_BIAS
+#define RT_STREAM_LEAF_BIAS 5
+#endif
+template <class Feed>
+RT_HD void walk_stream(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed) {
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
+  const double tmin = 0.001;
+  bool have = false;
+  uint32_t id = 0, i = begin, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0;
+  uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  double tmax = RT_INF, tm = 0.0;
+  auto rs = feed.ray(0);
+  LRay lr;
+  lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  for (;;) {
+    {  // lanes whose ray has left the section hand in the result
+      const uint32_t k = RTX_NODE_KIND((uint32_t)unit);
+      if (have && (k == PROG_NODE_END || k == PROG_NODE_SYNC)) { feed.commit(id, tmax, hit_kind, hit_ctx); have = false; }
+    }
+    if (feed.more() && RT_WAVE_COUNT(!have) >= RT_STREAM_REFILL) {
+      uint32_t nid = 0;
+      if (feed.take(!have, nid)) {
+        id = nid; rs = feed.ray(id); tm = feed.time(id);
+        feed.start(id, tmax, hit_kind, hit_ctx);
+        lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
+        cur = 0; i = begin; unit = prog[i]; have = true;
+      }
+    }
+    if (!RT_WAVE_ANY(have)) {
+      if (feed.more()) continue;
+      break;
+    }
+    const uint32_t kind_idx = (uint32_t)unit;
+    const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
+    int cls = CL_CHEAP;
+    if (!have || kind == PROG_NODE_END || kind == PROG_NODE_SYNC) cls = CL_DONE;
+    else if (kind == RTX_NODE_BOX) cls = CL_BOX;
+    else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    else if (kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
+    else if (kind == PROG_NODE_BOX6) cls = (lr.skip & 8u) ? CL_QUAD : CL_BOX6;
+    else if (kind == RTX_NODE_SPHERE) cls = CL_SPHERE;
+    else if (kind == RTX_NODE_QUAD) cls = CL_QUAD;
+    uint32_t next = i;
+    if (RT_WAVE_ANY(cls == CL_CHEAP)) {
+      if (cls == CL_CHEAP) {
+        if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+          cur = idx;
+          lr = lray_from_ops(prog + i + 1, count, rs.origin(), rs.dir());
+          next = i + 1 + PROG_XFORM_OP_UNITS * count;
+        } else {
+          next = i + prog_record_units(unit);  // filler (a section holds no media and no deferred part)
+        }
+      }
+    } else {
+      const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_d = RT_WAVE_COUNT(cls == CL_DONE);
+      if (n_x > 0 && n_x * RT_STREAM_LEAF_BIAS >= RT_WAVE_LANES - n_x - n_d) {
+        int nb, nd;
+        do {
+          if (have && RTX_NODE_KIND((uint32_t)unit) == RTX_NODE_BOX) {
+            const uint32_t i_pass = i + PROG_BOX_UNITS, i_fail = (uint32_t)(unit >> 32);
+            RT_TRACE_STEP(RTX_NODE_BOX);
+            const uint64_t u_pass = prog[i_pass], u_fail = prog[i_fail];
+            const bool pass = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax);
+            i = pass ? i_pass : i_fail;
+            unit = pass ? u_pass : u_fail;
+          }
+          const uint32_t k = RTX_NODE_KIND((uint32_t)unit);
+          nb = RT_WAVE_COUNT(have && k == RTX_NODE_BOX);
+          nd = RT_WAVE_COUNT(!have || k == PROG_NODE_END || k == PROG_NODE_SYNC);
+        } while (nb > 0 && nb * RT_STREAM_LEAF_BIAS >= RT_WAVE_LANES - nb - nd && !(feed.more() && nd >= RT_STREAM_REFILL));
+        continue;  // i and unit are current
+      }
+      const int n_ss = RT_WAVE_COUNT(cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(cls == CL_QUAD_AA), n_s = RT_WAVE_COUNT(cls == CL_SPHERE);
+      const int n_q = RT_WAVE_COUNT(cls == CL_QUAD), n_b = RT_WAVE_COUNT(cls == CL_BOX6);
+      int pick = CL_BOX, best_n = 0;
+      if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
+      if (n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
+      if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+      if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
+      if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
+      if (pick == CL_SPHERE_S) {
+        if (cls == CL_SPHERE_S) {
+          for (uint32_t k = 0; k < count; ++k) {
+            double t;
+            const DSphere sp = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
+            if (sphere_s_hit_t(sp, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1 + PROG_SPHERE_S_UNITS * count;
+        }
+      } else if (pick == CL_BOX6) {
+        if (cls == CL_BOX6) {
+          const DBox6 bx = *(const DBox6*)(prog + i + 1);
+RT_UNROLL
+          for (int f = 0; f < 6; ++f) {
+            double t;
+            if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; }
+          }
+          next = i + PROG_BOX6_UNITS;
+        }
+      } else if (pick == CL_QUAD_AA) {
+        if (cls == CL_QUAD_AA) {
+          for (uint32_t k = 0; k < count; ++k) {
+            double t;
+            const DAAQuad qa = *(const DAAQuad*)(prog + i + 1 + PROG_QUAD_AA_UNITS * k);
+            if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+          next = i + 1 + PROG_QUAD_AA_UNITS * count;
+        }
+      } else if (pick == CL_SPHERE) {
+        if (cls == CL_SPHERE) {
+          double t;
+          if (sphere_hit_t(S.spheres[idx], lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
+          next = i + 1;
+        }
+      } else if (pick == CL_QUAD) {
+        if (cls == CL_QUAD) {
+          uint32_t cnt = 1u, size = 1u;
+          if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
+          else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
+          for (uint32_t k = 0; k < cnt; ++k) {
+            double t;
+            if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+          next = i + size;
+        }
+      }
+    }
+    if (next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
+  }
+}
 
 // What the integrator needs from a hit: the fields of HitRecord (hittable.rs:9-17) in world space.
 struct Surface {

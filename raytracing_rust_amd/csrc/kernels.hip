@@ -84,7 +84,7 @@ struct WfCounters {
   uint32_t finished;    // set by k_wf_finish: the survivors have been run to their end
   uint32_t n_defer;     // rays of this iteration that entered the deferred section
   uint32_t work_main, work_tail;  // next queue entry to hand out in the two traversal launches of this iteration
-  uint32_t work_shade, _pad;      // the same for the shading launch
+  uint32_t work_shade, work_head; // the same for the shading launch and for the head-section launch
   unsigned long long next_path, total_paths;
 };
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
@@ -94,7 +94,7 @@ struct WfFrame {       // what a path index means: (sample offset, pixel rank); 
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
-  c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->_pad = 0;
+  c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
   c->next_path = 0; c->total_paths = total;
 }
 
@@ -112,7 +112,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->next_path += g;
   c->n_in = survivors + g;
   c->n_out = 0;
-  c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0;
+  c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
   stats[0] += g;  // only this single thread writes the path counter while a wavefront render runs
 }
 
@@ -174,7 +174,11 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   const uint32_t n = TAIL ? c->n_defer : c->n_in;
   if (blockIdx.x * blockDim.x >= n) return;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t first_unit = TAIL ? S.tail_begin : 0u;
+  // With a head section (walked by k_wf_stream before this launch) the world program is entered behind it, with the
+  // hit the head section found; media boundary programs sit in front of the world program, so a scene with general
+  // media still stages the image from its start.
+  const bool behind_head = !TAIL && S.head_end != 0;
+  const uint32_t first_unit = TAIL ? S.tail_begin : ((behind_head && MM != MEDIA_ALL) ? ((S.head_end + 1u) & ~1u) : 0u);
   const uint32_t end_unit = (!TAIL && S.tail_begin) ? S.tail_begin : S.n_units;
   const uint64_t* prog = S.prog;
 #if defined(RT_PROF)
@@ -228,8 +232,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       walk_program<MEDIA_NONE, false>(S, prog, S.tail_begin, active, rs, tm, 0.001, t_so_far, hit, false, rng, bounce, h.uv + 2 * (size_t)idx);
       if (active && hit_any(hit)) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
     } else {
-      const bool deferred = walk_program<MM, true>(S, prog, S.world_begin, active, rs, tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, rng, bounce,
-                                                     h.uv + 2 * (size_t)idx);
+      const double t0 = behind_head ? h.t[idx] : RT_INF;
+      const uint32_t kind0 = behind_head ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind_head ? h.ctx[idx] : 0u;
+      const bool deferred = walk_program<MM, true>(S, prog, behind_head ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
+                                                   MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0);
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
       if (collect) {
         const unsigned long long m = __ballot(active && deferred);
@@ -265,6 +271,71 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     atomicAdd(&g_prof[(threadIdx.x / 10) * 16 + threadIdx.x % 10], sum);
   }
 #endif
+}
+
+// A section of the program walked as a stream (walk_stream): the head section of the world program for every queued
+// path (TAIL = false; it leaves its closest hit in the hit arrays, where the world-program launch picks it up), or the
+// deferred section for the rays of the defer list (TAIL = true; it starts from the hit found so far).  Queue entries
+// are taken in per-wave batches (one atomic each, shrinking towards the end of the queue) and handed to lanes as they
+// run out of work.
+struct QueueFeed {
+  const double* qf; size_t cap;
+  const uint32_t* list;            // defer list, or null: entry k is path k
+  double* ht; uint32_t* hk; uint32_t* hc;
+  uint32_t* work; uint32_t n, n_waves, lane;
+  uint32_t wnext, wend, seen;      // this wave's batch [wnext, wend) and the queue counter as last seen
+  bool more_, from_hits;
+  __device__ bool more() const { return more_; }
+  __device__ bool take(bool want, uint32_t& id) {
+    if (wnext >= wend) {
+      uint32_t batch = ((n - seen) / (2u * n_waves)) & ~63u;
+      batch = batch < 64u ? 64u : (batch > 4u * RT_WAVE_BATCH ? 4u * RT_WAVE_BATCH : batch);
+      uint32_t b = 0;
+      if (lane == 0) b = atomicAdd(work, batch);
+      b = __shfl(b, 0);
+      seen = b < n ? b : n;
+      if (b >= n) { more_ = false; return false; }
+      wnext = b; wend = b + batch < n ? b + batch : n;
+    }
+    const unsigned long long m = __ballot(want);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t avail = wend - wnext, asked = (uint32_t)__popcll(m);
+    const uint32_t k = wnext + rank;
+    wnext += asked < avail ? asked : avail;
+    if (want && rank < avail) { id = list ? list[k] : k; return true; }
+    return false;
+  }
+  __device__ RayMem ray(uint32_t id) const { RayMem r; r.f = qf + id; r.cap = cap; return r; }
+  __device__ double time(uint32_t id) const { return qf[id + 6 * cap]; }
+  __device__ void start(uint32_t id, double& tmax, uint32_t& kind, uint32_t& ctx) const {
+    if (from_hits) { tmax = ht[id]; kind = hk[id]; ctx = hc[id]; }
+    else { tmax = RT_INF; kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0); ctx = 0; }
+  }
+  __device__ void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { ht[id] = tmax; hk[id] = kind; hc[id] = ctx; }
+};
+
+template <bool USE_LDS, bool TAIL>
+__global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t cap, WfCounters* c, WfQueue q, WfHits h,
+                                                    const uint32_t* __restrict__ defer_list) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
+  const uint32_t n = TAIL ? c->n_defer : c->n_in;
+  if (blockIdx.x * blockDim.x >= n) return;
+  const uint32_t first_unit = TAIL ? S.tail_begin : 0u;
+  const uint32_t end_unit = TAIL ? S.n_units : ((S.head_end + 2u) & ~1u);   // the SYNC that ends the head section included
+  const uint64_t* prog = S.prog;
+  if (USE_LDS) {
+    const uint4* src = (const uint4*)(S.prog + first_unit);
+    uint4* dst = (uint4*)lds_prog;
+    for (uint32_t k = threadIdx.x; k < (end_unit - first_unit) / 2; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    prog = lds_prog - first_unit;
+  }
+  QueueFeed feed;
+  feed.qf = q.f; feed.cap = cap; feed.list = TAIL ? defer_list : nullptr;
+  feed.ht = h.t; feed.hk = h.kind_idx; feed.hc = h.ctx;
+  feed.work = TAIL ? &c->work_tail : &c->work_head; feed.n = n; feed.n_waves = gridDim.x * (blockDim.x / 64u); feed.lane = threadIdx.x & 63u;
+  feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
+  walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
 }
 
 // Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
@@ -485,15 +556,15 @@ __global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ accu
 
 static thread_local std::string g_error;
 
-struct TimedSpan { hipEvent_t e0, e1; int what; };  // what: 0 = whole render call, 1 = traversal kernel
+struct TimedSpan { hipEvent_t e0, e1; int what; };  // what: 0 = whole render call, 1 = world-program traversal, 2 = deferred section, 3 = head section
 
 struct rtx_context {
   int device = 0;
   int n_cus = 256;
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
-  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0;
-  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0;
+  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0;
+  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
   // wavefront workspace (allocated on first use, kept for the context's lifetime)
@@ -537,7 +608,8 @@ static void drain_events(rtx_context* ctx) {
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       if (p.what == 0) { ctx->render_ms += ms; ctx->last_kernel_ms = ms; ctx->launches += 1; }
       else if (p.what == 1) { ctx->traverse_ms += ms; ctx->traverse_launches += 1; }
-      else { ctx->tail_ms += ms; ctx->tail_launches += 1; }
+      else if (p.what == 2) { ctx->tail_ms += ms; ctx->tail_launches += 1; }
+      else { ctx->head_ms += ms; ctx->head_launches += 1; }
     }
     ctx->free_events.push_back(p.e0); ctx->free_events.push_back(p.e1);
   }
@@ -688,6 +760,8 @@ static rtx_status wf_ensure(rtx_context* ctx) {
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   ctx->wf_cap = cap;
   return RTX_OK;
 }
@@ -717,10 +791,26 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
   // defer buffers; the deferred section's own program
   const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
-  const size_t main_bytes = (size_t)(tail_begin ? tail_begin : n_units) * 8;
+  // Stream walks (k_wf_stream) of the head and of the deferred section.  Measured: a section whose program sits in LDS
+  // is walked faster per ray inside the world-program kernel (its box loops leave issue slots that the waves in
+  // sphere and medium code use; on the final scene the streamed form is 6 % slower over all), a section walked from
+  // global memory is latency bound and gains from refilled lanes (stress scene: +34 %).  So a section is streamed when
+  // it does not fit LDS; RTX_WF_STREAM=1 streams every section, RTX_WF_STREAM=0 none.
+  const char* stream_env = getenv("RTX_WF_STREAM");
+  const int stream_mode = stream_env ? atoi(stream_env) : -1;  // -1: by size
+  const size_t head_bytes = sc->dev.head_end ? (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 : 0;
+  const bool head_lds = head_bytes <= kLdsBudget;
   const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
+  const bool tail_lds = tail_bytes <= kLdsBudget;
+  const bool stream_head = sc->dev.head_end != 0 && (stream_mode == 1 || (stream_mode < 0 && !head_lds));
+  const bool stream_tail = tail_begin != 0 && (stream_mode == 1 || (stream_mode < 0 && !tail_lds));
+  const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
+  Scene dev = sc->dev;
+  dev.head_end = head_end;
+  const uint32_t main_first = (head_end && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
+  const size_t main_bytes = (size_t)((tail_begin ? tail_begin : n_units) - main_first) * 8;
   const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
-  const bool main_lds = main_bytes + defer_bytes <= kLdsBudget, tail_lds = tail_bytes <= kLdsBudget;
+  const bool main_lds = main_bytes + defer_bytes <= kLdsBudget;
   // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
   const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
   auto k_main = main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
@@ -740,15 +830,28 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin);
       TimedSpan sp;
       const bool timed = span_begin(ctx, stream, sp, 1);
-      hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+      if (head_end) {  // the head section of the world program, streamed
+        TimedSpan sh;
+        const bool timed_head = span_begin(ctx, stream, sh, 3);
+        if (head_lds)
+          hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
+        else
+          hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
+        if (timed_head) span_end(ctx, stream, sh);
+      }
+      hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
       if (timed) span_end(ctx, stream, sp);
       if (sc->dev.tail_begin) {  // the deferred section for the rays that passed its root box
         TimedSpan st;
         const bool timed_tail = span_begin(ctx, stream, st, 2);
-        if (tail_lds)
-          hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+        if (stream_tail && tail_lds)
+          hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
+        else if (stream_tail)
+          hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
+        else if (tail_lds)
+          hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
         else
-          hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, sc->dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
+          hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
         if (timed_tail) span_end(ctx, stream, st);
       }
       hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
@@ -820,6 +923,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
+  sc->dev.head_end = prog.head_end; sc->dev._pad_scene = 0;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
@@ -965,6 +1069,7 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
+  out->head_ms = ctx->head_ms; out->head_launches = ctx->head_launches;
   return RTX_OK;
 }
 
@@ -974,7 +1079,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)));
-  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0;
+  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0;
   return RTX_OK;
 }
 

@@ -111,6 +111,19 @@ def hostsim_first_hit(desc, rays):
     return out
 
 
+def hostsim_first_hit_staged(desc, rays):
+    """First hits through the stages of the wavefront pipeline (streamed head section, rest of the world program,
+    streamed deferred section).  Returns (aov dict, number of rays that went through a stream walk)."""
+    r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+    n = r.shape[0]
+    out = {"t": np.empty(n), "normal": np.empty((n, 3)), "prim_id": np.empty(n, dtype=np.uint32),
+           "mat_id": np.empty(n, dtype=np.uint32), "front": np.empty(n, dtype=np.uint8)}
+    k = hostsim_lib().sim_first_hit_staged(C.byref(desc), dptr(r), n, dptr(out["t"]), dptr(out["normal"]),
+                                           out["prim_id"].ctypes.data_as(PU32), out["mat_id"].ctypes.data_as(PU32),
+                                           out["front"].ctypes.data_as(PU8))
+    return out, k
+
+
 def oracle_render(g, world, lights, cam, sample_begin=0, sample_end=None, rect=None, seed=7, use_lights=True, threads=8):
     o = OracleOpts()
     o.sample_begin = sample_begin

@@ -47,6 +47,76 @@ int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, doub
   return 0;
 }
 
+// The wavefront pipeline's three-stage first hit, stage by stage as the GPU launches it: the head section as a stream
+// (walk_stream), the rest of the world program from the hit found so far with deferred rays only noted, and the
+// deferred section as a stream over the noted rays.  Same outputs as sim_first_hit; returns the number of rays
+// that went through a stream walk, -1 if the program has neither a head nor a deferred section.
+struct HostFeed {
+  const double* rays; const uint32_t* list; size_t n, next;
+  Hit* hits; bool from_hits;
+  bool more() const { return next < n; }
+  bool take(bool want, uint32_t& id) { if (!want || next >= n) return false; id = list ? list[next] : (uint32_t)next; ++next; return true; }
+  RayRegs ray(uint32_t id) const {
+    RayRegs rs;
+    if (n == 0) { rs.r.o = v3(0, 0, 0); rs.r.d = v3(0, 0, 1); rs.r.tm = 0; return rs; }
+    const double* r = rays + 7 * (size_t)id;
+    rs.r.o = v3(r[0], r[1], r[2]); rs.r.d = v3(r[3], r[4], r[5]); rs.r.tm = r[6];
+    return rs;
+  }
+  double time(uint32_t id) const { return rays[7 * (size_t)id + 6]; }
+  void start(uint32_t id, double& tmax, uint32_t& kind, uint32_t& ctx) const {
+    if (from_hits) { tmax = hits[id].t; kind = hits[id].kind_idx; ctx = hits[id].ctx; }
+    else { tmax = RT_INF; kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0); ctx = 0; }
+  }
+  void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { hits[id].t = tmax; hits[id].kind_idx = kind; hits[id].ctx = ctx; }
+};
+
+int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
+                         uint32_t* mat_id, uint8_t* front) {
+  CompiledProgram prog;
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  const Scene S = prog.host_view(*desc);
+  if (!S.head_end && !S.tail_begin) return -1;
+  std::vector<Hit> hits(n);
+  std::vector<uint32_t> deferred;
+  int streamed = 0;
+  if (S.head_end) {
+    HostFeed feed{rays, nullptr, n, 0, hits.data(), false};
+    walk_stream(S, S.prog, S.world_begin, feed);
+    streamed += (int)n;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    HostFeed one{rays, nullptr, n, 0, hits.data(), false};
+    const RayRegs rs = one.ray((uint32_t)i);
+    Hit h;
+    const double t0 = S.head_end ? hits[i].t : RT_INF;
+    const uint32_t k0 = S.head_end ? hits[i].kind_idx : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), c0 = S.head_end ? hits[i].ctx : 0u;
+    const bool d = walk_program<MEDIA_NONE, true>(S, S.prog, S.head_end ? S.head_end + 1u : S.world_begin, true, rs, rs.r.tm, 0.001, t0, h, false,
+                                                  PathRng(), 0, nullptr, k0, c0);
+    hits[i] = h;
+    if (d) deferred.push_back((uint32_t)i);
+  }
+  if (S.tail_begin) {
+    HostFeed feed{rays, deferred.data(), deferred.size(), 0, hits.data(), true};
+    walk_stream(S, S.prog, S.tail_begin, feed);
+    streamed += (int)deferred.size();
+  }
+  for (size_t i = 0; i < n; ++i) {
+    HostFeed one{rays, nullptr, n, 0, hits.data(), false};
+    const Ray ray = one.ray((uint32_t)i).r;
+    const Hit h = hits[i];
+    const bool any = hit_any(h);
+    Surface sf;
+    if (any) resolve_hit(S, ray, h, false, nullptr, sf);
+    if (t) t[i] = any ? h.t : RT_INF;
+    if (normal) { normal[3 * i] = any ? sf.n.x : 0; normal[3 * i + 1] = any ? sf.n.y : 0; normal[3 * i + 2] = any ? sf.n.z : 0; }
+    if (prim_id) prim_id[i] = any ? sf.prim_id : 0xFFFFFFFFu;
+    if (mat_id) mat_id[i] = any ? sf.mat : 0xFFFFFFFFu;
+    if (front) front[i] = any ? (sf.front ? 1 : 0) : 0;
+  }
+  return streamed;
+}
+
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }

@@ -122,6 +122,27 @@ def test_wavefront_and_fused_pipelines_trace_the_same_paths(gpu_ctx, name, width
     scene.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
+    """The head section of the world program (the ground BVH of the final scene) and the deferred section (its sphere
+    cluster) can be walked per ray or as streams with refilled lanes (RTX_WF_STREAM=0 / 1; by default the choice
+    follows the size of the section).  Either way the wavefront pipeline must trace the fused pipeline's paths."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("final", gp, width=160, spp=16, depth=40)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=78, pipeline=_capi.PIPELINE_FUSED))
+    sa = gpu_ctx.stats()
+    monkeypatch.setenv("RTX_WF_STREAM", mode)
+    gpu_ctx.reset_stats()
+    b = scene.render(cam, rt.render_opts(cam, seed=78, pipeline=_capi.PIPELINE_WAVEFRONT))
+    sb = gpu_ctx.stats()
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    assert (sb["head_launches"] > 0) == (mode == "1")
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 @pytest.mark.parametrize("recipe", [recipes.large_bvh_beyond_lds, recipes.empty_lists_and_media, recipes.nested_transforms],
                          ids=lambda r: r.__name__)
 def test_pipelines_agree_on_recipes(gpu_ctx, recipe):

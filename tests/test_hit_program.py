@@ -46,6 +46,30 @@ def test_recipes_bit_exact(recipe):
     assert np.isfinite(a["t"]).sum() > 50, "recipe rays should hit something"
 
 
+@pytest.mark.parametrize("name,width", [("final", 160), ("stress", 200)])
+def test_staged_walk_with_streamed_sections_is_the_same_walk(name, width):
+    """The wavefront pipeline walks the world program in stages: the head section (the world's first large box subtree)
+    as a stream in which a lane takes the next ray as soon as its own has left the section, the rest of the program
+    from the hit found so far, the deferred section as a stream over the rays that entered it.  First hits must be
+    those of the undivided walk, bit for bit, and both kinds of section must actually occur."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build(name, gp, width=width, n_prims=20000)
+    d = rt.flatten(gp, wp, lp)
+    rng = np.random.default_rng(12)
+    rays = rt.pixel_center_rays(cam, time=0.4)
+    # secondary-like rays: from random points of the scene's extent in random directions
+    lo, hi = (np.array([-1000.0, 0.0, -1000.0]), np.array([1000.0, 600.0, 1000.0])) if name == "final" else (np.full(3, -1000.0), np.full(3, 1000.0))
+    sec = np.concatenate([rng.uniform(lo, hi, (6000, 3)), rng.normal(size=(6000, 3)), rng.uniform(0, 1, (6000, 1))], axis=1)
+    rays = np.concatenate([rays, sec])
+    whole = H.hostsim_first_hit(d, rays)
+    staged, streamed = H.hostsim_first_hit_staged(d, rays)
+    H.assert_aov_equal(whole, staged, name)
+    assert streamed >= len(rays)                                  # the head section saw every ray
+    if name == "final":
+        assert streamed > len(rays) + 100                         # and some rays entered the deferred section
+    assert np.isfinite(whole["t"]).sum() > 1000
+
+
 def test_final_scene_bvh_shape():
     """400 leaves -> 511 nodes, 1000 leaves -> 1023 nodes (f(1)=f(2)=1, f(n)=1+f(n/2)+f(n-n/2)), bvh.rs:26-71."""
     g = rt.Graph()
