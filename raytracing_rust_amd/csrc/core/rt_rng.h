@@ -113,8 +113,10 @@ RT_HD V3 random_cosine_direction(PathRng& r) {
   rng_next2(r, r1, r2);
   double phi = 2.0 * RT_PI * r1;
   double s = sqrt(r2);
-  double x = cos(phi) * s;
-  double y = sin(phi) * s;
+  double sn, cs;
+  rt_sincos(phi, sn, cs);
+  double x = cs * s;
+  double y = sn * s;
   double z = sqrt(1.0 - r2);
   return v3(x, y, z);
 }

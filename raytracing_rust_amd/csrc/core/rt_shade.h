@@ -138,8 +138,10 @@ RT_HD V3 sphere_random(const rtx_sphere& s, const V3& origin, PathRng& rng) {
   double z = 1.0 + r2 * (sqrt(1.0 - s.radius * s.radius / dist2) - 1.0);
   double phi = 2.0 * RT_PI * r1;
   double sq = sqrt(1.0 - z * z);
-  double x = cos(phi) * sq;
-  double y = sin(phi) * sq;
+  double sn, cs;
+  rt_sincos(phi, sn, cs);
+  double x = cs * sq;
+  double y = sn * sq;
   return onb_local(onb, v3(x, y, z));
 }
 // Quad::pdf_value, quad.rs:102-116
