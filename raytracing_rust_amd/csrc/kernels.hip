@@ -86,7 +86,15 @@ struct WfCounters {
   uint32_t work_main, work_tail;  // next queue entry to hand out in the two traversal launches of this iteration
   uint32_t work_shade, work_head; // the same for the shading launch and for the head-section launch
   unsigned long long next_path, total_paths;
+  // Device-side timing of the world-program traversal launches (wall_clock64 ticks): first block in, last block out
+  // of the current launch; sum and number of the launches completed so far.  HIP events cannot time a kernel while
+  // other pipelines share the GPU: they would include the wait for a free CU.
+  unsigned long long k1_start, k1_end, k1_sum, k1_count;
 };
+__device__ __forceinline__ void wf_flush_timing(WfCounters* c) {  // one thread, between launches
+  if (c->k1_end > c->k1_start) { c->k1_sum += c->k1_end - c->k1_start; c->k1_count += 1; }
+  c->k1_start = ~0ull; c->k1_end = 0ull;
+}
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
   int x0, y0, w, h, sample_begin;
   uint32_t per_sample;  // w * h
@@ -96,6 +104,7 @@ __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
   c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
   c->next_path = 0; c->total_paths = total;
+  c->k1_start = ~0ull; c->k1_end = 0ull; c->k1_sum = 0ull; c->k1_count = 0ull;
 }
 
 // One thread: decide how many new camera paths top the queue up and flip the in/out roles.  New paths take the
@@ -103,6 +112,7 @@ __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
 __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, unsigned long long* __restrict__ stats) {
   const uint32_t survivors = c->finished ? 0u : c->n_out;
   c->finished = 0;
+  wf_flush_timing(c);
   const unsigned long long remaining = c->total_paths - c->next_path;
   const unsigned long long room = cap - survivors;
   uint32_t g = (uint32_t)(remaining < room ? remaining : room);
@@ -113,7 +123,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->n_in = survivors + g;
   c->n_out = 0;
   c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
-  stats[0] += g;  // only this single thread writes the path counter while a wavefront render runs
+  if (g) atomicAdd(&stats[0], (unsigned long long)g);  // two pipelines may be preparing at the same time
 }
 
 // Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, pixel), pixels enumerated tile by tile
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
   const uint32_t n = TAIL ? c->n_defer : c->n_in;
   if (blockIdx.x * blockDim.x >= n) return;
+  if (!TAIL && threadIdx.x == 0) atomicMin(&c->k1_start, (unsigned long long)wall_clock64());
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // With a head section (walked by k_wf_stream before this launch) the world program is entered behind it, with the
   // hit the head section found; media boundary programs sit in front of the world program, so a scene with general
@@ -262,6 +273,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     if (lane == 0) at = atomicAdd(&c->n_defer, n_wait);
     at = __shfl(at, 0);
     if (lane < n_wait) defer_list[at + lane] = wave_defer[lane];
+  }
+  if (!TAIL) {
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&c->k1_end, (unsigned long long)wall_clock64());
   }
 #if defined(RT_PROF)
   __syncthreads();
@@ -419,6 +434,7 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
                                                    int use_lights, uint32_t threshold, WfCounters* c, WfQueue qin,
                                                    double* __restrict__ accum, unsigned long long* __restrict__ stats) {
   const uint32_t n = c->n_out;  // survivors of the last shading launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) wf_flush_timing(c);
   if (n == 0 || n > threshold || c->next_path != c->total_paths) return;
   if (blockIdx.x * blockDim.x >= n) return;
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,24 +574,32 @@ static thread_local std::string g_error;
 
 struct TimedSpan { hipEvent_t e0, e1; int what; };  // what: 0 = whole render call, 1 = world-program traversal, 2 = deferred section, 3 = head section
 
+#define RT_WF_MAX_LANES 8
 struct rtx_context {
   int device = 0;
   int n_cus = 256;
+  double wall_clock_khz = 100000.0;  // rate of wall_clock64()
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
   double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0;
   uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
-  // wavefront workspace (allocated on first use, kept for the context's lifetime)
-  uint32_t wf_cap = 0;
-  WfQueue wf_q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  WfHits wf_hits = {nullptr, nullptr, nullptr, nullptr};
-  uint32_t* wf_defer = nullptr;  // queue indices of the rays that entered the deferred section
-  WfCounters* wf_c = nullptr;
-  WfCounters* wf_host = nullptr;  // pinned, two slots
-  hipEvent_t wf_ev[2] = {nullptr, nullptr};
-  std::vector<void*> wf_allocs;
+  // wavefront workspace (allocated on first use, kept for the context's lifetime): up to two independent pipelines
+  bool wf_ready = false;
+  struct WfLane {
+    uint32_t cap = 0;              // paths in flight its buffers hold
+    std::vector<void*> allocs;
+    WfQueue q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    WfHits hits = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* defer = nullptr;     // queue indices of the rays that entered the deferred section
+    WfCounters* c = nullptr;
+    WfCounters* host = nullptr;    // pinned, two slots
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;  // the second pipeline runs on a stream of its own
+    hipEvent_t joined = nullptr;
+  } wf[RT_WF_MAX_LANES];
+  hipEvent_t wf_fork = nullptr;
 };
 
 struct rtx_scene {
@@ -738,37 +762,57 @@ static const size_t kLdsBudget = 160 * 1024 - 4096;  // the tuning build keeps 4
 static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, one persistent workgroup per CU
 #endif
 
-static rtx_status wf_ensure(rtx_context* ctx) {
-  if (ctx->wf_cap) return RTX_OK;
-  uint32_t cap = 1u << 23;  // paths in flight: 1.8 GB of queues; measured plateau of throughput vs. capacity
-  if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
-  cap = (cap + 255u) & ~255u;
-  auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) ctx->wf_allocs.push_back(*p); return e; };
-  for (int k = 0; k < 2; ++k) {
-    HIP_TRY(ctx, A((void**)&ctx->wf_q[k].f, (size_t)cap * 10 * sizeof(double)));
-    HIP_TRY(ctx, A((void**)&ctx->wf_q[k].u, (size_t)cap * 3 * sizeof(uint32_t)));
+// Workspace of pipeline `lane` for at least `want` paths in flight (a multiple of 256).  Buffers only grow; they are
+// kept for the context's lifetime.
+static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
+  if (!ctx->wf_ready) {
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
+    ctx->wf_ready = true;
   }
-  HIP_TRY(ctx, A((void**)&ctx->wf_hits.t, (size_t)cap * sizeof(double)));
-  HIP_TRY(ctx, A((void**)&ctx->wf_hits.kind_idx, (size_t)cap * sizeof(uint32_t)));
-  HIP_TRY(ctx, A((void**)&ctx->wf_hits.ctx, (size_t)cap * sizeof(uint32_t)));
-  HIP_TRY(ctx, A((void**)&ctx->wf_hits.uv, (size_t)cap * 2 * sizeof(double)));
-  HIP_TRY(ctx, A((void**)&ctx->wf_c, sizeof(WfCounters)));
-  HIP_TRY(ctx, hipHostMalloc((void**)&ctx->wf_host, 2 * sizeof(WfCounters), hipHostMallocDefault));
-  for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_ev[k], hipEventDisableTiming));
-  HIP_TRY(ctx, A((void**)&ctx->wf_defer, (size_t)cap * sizeof(uint32_t)));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  ctx->wf_cap = cap;
+  rtx_context::WfLane& L = ctx->wf[lane];
+  if (!L.host) {
+    HIP_TRY(ctx, hipMalloc((void**)&L.c, sizeof(WfCounters)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&L.host, 2 * sizeof(WfCounters), hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) HIP_TRY(ctx, hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&L.joined, hipEventDisableTiming));
+    if (lane > 0) HIP_TRY(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+  }
+  if (L.cap >= want) return RTX_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());  // nothing may still be reading the buffers that are replaced
+  for (void* p : L.allocs) (void)hipFree(p);
+  L.allocs.clear();
+  L.cap = 0;
+  auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) L.allocs.push_back(*p); return e; };
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(ctx, A((void**)&L.q[k].f, (size_t)want * 10 * sizeof(double)));
+    HIP_TRY(ctx, A((void**)&L.q[k].u, (size_t)want * 3 * sizeof(uint32_t)));
+  }
+  HIP_TRY(ctx, A((void**)&L.hits.t, (size_t)want * sizeof(double)));
+  HIP_TRY(ctx, A((void**)&L.hits.kind_idx, (size_t)want * sizeof(uint32_t)));
+  HIP_TRY(ctx, A((void**)&L.hits.ctx, (size_t)want * sizeof(uint32_t)));
+  HIP_TRY(ctx, A((void**)&L.hits.uv, (size_t)want * 2 * sizeof(double)));
+  HIP_TRY(ctx, A((void**)&L.defer, (size_t)want * sizeof(uint32_t)));
+  L.cap = want;
   return RTX_OK;
 }
 
 // The wavefront loop: [prepare, ray generation, traversal, shading+compaction] per iteration until every camera path
 // of the call has ended.  Iterations are enqueued in chunks; the counters of chunk k are inspected while chunk k+1 is
 // already enqueued, so the GPU never waits for the host.  Kernels of an iteration with nothing to do exit at once.
+//
+// A large call is split by sample index between up to four such pipelines, one on the caller's stream and the others
+// on streams of the library (forked from and joined to the caller's stream with events): each kernel of an iteration
+// depends on the one before it, so a single pipeline leaves CUs idle while every launch drains; independent pipelines
+// fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s): 1 pipeline of 8 M paths in
+// flight 1198, of 32 M 1305; 2 x 8 M 1268; 4 x 8 M 1348; 4 x 16 M 1372; 4 x 32 M 1384.  Default: one pipeline per 4 M
+// camera paths of the call, at most four, each holding at most 16 M paths (3.7 GB) and no more than its share of the
+// call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
   static unsigned v = 0;
   if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
@@ -777,16 +821,24 @@ static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a mul
 
 static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
   rtx_context* ctx = sc->ctx;
-  rtx_status st = wf_ensure(ctx);
-  if (st != RTX_OK) return st;
-  const uint32_t cap = ctx->wf_cap;
-  WfFrame fr;
-  fr.x0 = o->x0; fr.y0 = o->y0; fr.w = o->x1 - o->x0; fr.h = o->y1 - o->y0; fr.sample_begin = o->sample_begin;
-  const unsigned long long per_sample = (unsigned long long)fr.w * (unsigned long long)fr.h;
+  const int n_samples = o->sample_end - o->sample_begin;
+  const unsigned long long per_sample = (unsigned long long)(o->x1 - o->x0) * (unsigned long long)(o->y1 - o->y0);
+  const unsigned long long call_paths = per_sample * (unsigned long long)std::max(n_samples, 0);
+  const char* lanes_env = getenv("RTX_WF_LANES");
+  const int want_lanes = lanes_env ? atoi(lanes_env) : (int)std::min<unsigned long long>(4ull, call_paths >> 22);
+  const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
+  uint32_t cap = 1u << 24;
+  if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
+  {  // no more than a pipeline's share of the call needs (whole sample indices; at least 64 K)
+    const unsigned long long share = per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes);
+    if (share < cap) cap = (uint32_t)std::max<unsigned long long>(share, 65536ull);
+  }
+  cap = (cap + 255u) & ~255u;
   if (per_sample + cap >= (1ull << 32)) return fail(ctx, RTX_ERR_UNSUPPORTED, "rtx_render: more than 2^32 pixels in one call");
-  fr.per_sample = (uint32_t)per_sample;
-  // a path of depth 0 is black (camera.rs:169-171): nothing to trace
-  const unsigned long long total = cam->max_depth > 0 ? per_sample * (unsigned long long)(o->sample_end - o->sample_begin) : 0ull;
+  for (int l = 0; l < n_lanes; ++l) {
+    rtx_status st = wf_ensure(ctx, l, cap);
+    if (st != RTX_OK) return st;
+  }
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
   // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
   // defer buffers; the deferred section's own program
@@ -819,54 +871,82 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
   const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
   const unsigned shade_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 16u);
-  hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, stream, ctx->wf_c, total);
+  const unsigned long long seed = (unsigned long long)o->seed;
+
+  struct Run { rtx_context::WfLane* L; hipStream_t s; WfFrame fr; int cur, k; bool done; };
+  Run runs[RT_WF_MAX_LANES];
+  if (n_lanes > 1) HIP_TRY(ctx, hipEventRecord(ctx->wf_fork, stream));
+  for (int l = 0; l < n_lanes; ++l) {
+    Run& r = runs[l];
+    r.L = &ctx->wf[l]; r.s = l == 0 ? stream : r.L->stream; r.cur = 0; r.k = 0; r.done = false;
+    // sample indices of this pipeline: an equal share of the call's range
+    const int sb = o->sample_begin + (int)((long long)n_samples * l / n_lanes), se = o->sample_begin + (int)((long long)n_samples * (l + 1) / n_lanes);
+    r.fr.x0 = o->x0; r.fr.y0 = o->y0; r.fr.w = o->x1 - o->x0; r.fr.h = o->y1 - o->y0; r.fr.sample_begin = sb; r.fr.per_sample = (uint32_t)per_sample;
+    // a path of depth 0 is black (camera.rs:169-171): nothing to trace
+    const unsigned long long total = cam->max_depth > 0 ? per_sample * (unsigned long long)(se - sb) : 0ull;
+    if (l > 0) HIP_TRY(ctx, hipStreamWaitEvent(r.s, ctx->wf_fork, 0));
+    hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, r.s, r.L->c, total);
+  }
   const int chunk = 8;
-  int cur = 0;  // queue the traversal reads in the next iteration
-  bool done = false;
-  for (int k = 0; !done; ++k) {
-    for (int it = 0; it < chunk; ++it) {
-      WfQueue qin = ctx->wf_q[cur], qout = ctx->wf_q[cur ^ 1];
-      hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, stream, ctx->wf_c, cap, fr.per_sample, ctx->d_counters);
-      hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, stream, *cam, fr, (unsigned long long)o->seed, cap, ctx->wf_c, qin);
-      TimedSpan sp;
-      const bool timed = span_begin(ctx, stream, sp, 1);
-      if (head_end) {  // the head section of the world program, streamed
-        TimedSpan sh;
-        const bool timed_head = span_begin(ctx, stream, sh, 3);
-        if (head_lds)
-          hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
-        else
-          hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
-        if (timed_head) span_end(ctx, stream, sh);
+  for (bool all_done = false; !all_done;) {
+    all_done = true;
+    for (int l = 0; l < n_lanes; ++l) {
+      Run& r = runs[l];
+      if (r.done) continue;
+      rtx_context::WfLane& L = *r.L;
+      hipStream_t s = r.s;
+      for (int it = 0; it < chunk; ++it) {
+        WfQueue qin = L.q[r.cur], qout = L.q[r.cur ^ 1];
+        hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, L.c, cap, r.fr.per_sample, ctx->d_counters);
+        hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, s, *cam, r.fr, seed, cap, L.c, qin);
+        if (head_end) {  // the head section of the world program, streamed
+          TimedSpan sh;
+          const bool timed_head = span_begin(ctx, s, sh, 3);
+          if (head_lds)
+            hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else
+            hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
+          if (timed_head) span_end(ctx, s, sh);
+        }
+        hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+        if (tail_begin) {  // the deferred section for the rays that passed its root box
+          TimedSpan st;
+          const bool timed_tail = span_begin(ctx, s, st, 2);
+          if (stream_tail && tail_lds)
+            hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (stream_tail)
+            hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (tail_lds)
+            hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+          else
+            hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+          if (timed_tail) span_end(ctx, s, st);
+        }
+        hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, L.c, qin, L.hits, qout, accum_dev, ctx->d_counters);
+        r.cur ^= 1;
       }
-      hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
-      if (timed) span_end(ctx, stream, sp);
-      if (sc->dev.tail_begin) {  // the deferred section for the rays that passed its root box
-        TimedSpan st;
-        const bool timed_tail = span_begin(ctx, stream, st, 2);
-        if (stream_tail && tail_lds)
-          hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
-        else if (stream_tail)
-          hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer);
-        else if (tail_lds)
-          hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
-        else
-          hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, stream, dev, cap, (unsigned long long)o->seed, ctx->wf_c, qin, ctx->wf_hits, ctx->wf_defer, ctx->d_counters);
-        if (timed_tail) span_end(ctx, stream, st);
+      hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipMemcpyAsync(&L.host[r.k & 1], L.c, sizeof(WfCounters), hipMemcpyDeviceToHost, s));
+      HIP_TRY(ctx, hipEventRecord(L.ev[r.k & 1], s));
+      if (r.k > 0) {
+        HIP_TRY(ctx, hipEventSynchronize(L.ev[(r.k - 1) & 1]));
+        const WfCounters& c = L.host[(r.k - 1) & 1];
+        r.done = c.n_out == 0 && c.next_path == c.total_paths;
+        if (r.done) {  // the traversal launches of this pipeline, timed on the device
+          ctx->traverse_ms += (double)c.k1_sum / ctx->wall_clock_khz;
+          ctx->traverse_launches += c.k1_count;
+        }
       }
-      hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, ctx->wf_c, qin, ctx->wf_hits, qout, accum_dev, ctx->d_counters);
-      cur ^= 1;
+      r.k += 1;
+      if (!r.done) all_done = false;
+      if (ctx->pending.size() > 2048) drain_events(ctx);
     }
-    hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, stream, sc->dev, *cam, cap, (unsigned long long)o->seed, use_lights, (uint32_t)finish_threshold(), ctx->wf_c, ctx->wf_q[cur], accum_dev, ctx->d_counters);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(&ctx->wf_host[k & 1], ctx->wf_c, sizeof(WfCounters), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->wf_ev[k & 1], stream));
-    if (k > 0) {
-      HIP_TRY(ctx, hipEventSynchronize(ctx->wf_ev[(k - 1) & 1]));
-      const WfCounters& c = ctx->wf_host[(k - 1) & 1];
-      done = c.n_out == 0 && c.next_path == c.total_paths;
-    }
-    if (ctx->pending.size() > 2048) drain_events(ctx);
+  }
+  // the caller's stream continues when both pipelines are through
+  for (int l = 1; l < n_lanes; ++l) {
+    HIP_TRY(ctx, hipEventRecord(runs[l].L->joined, runs[l].s));
+    HIP_TRY(ctx, hipStreamWaitEvent(stream, runs[l].L->joined, 0));
   }
   return RTX_OK;
 }
@@ -893,6 +973,8 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
     return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
   }
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) ctx->wall_clock_khz = (double)khz;
   *out = ctx;
   return RTX_OK;
 }
@@ -903,9 +985,15 @@ void rtx_context_destroy(rtx_context* ctx) {
   (void)hipDeviceSynchronize();
   drain_events(ctx);
   for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
-  for (void* p : ctx->wf_allocs) (void)hipFree(p);
-  if (ctx->wf_host) (void)hipHostFree(ctx->wf_host);
-  for (int k = 0; k < 2; ++k) if (ctx->wf_ev[k]) (void)hipEventDestroy(ctx->wf_ev[k]);
+  for (auto& L : ctx->wf) {
+    for (void* p : L.allocs) (void)hipFree(p);
+    if (L.c) (void)hipFree(L.c);
+    if (L.host) (void)hipHostFree(L.host);
+    for (int k = 0; k < 2; ++k) if (L.ev[k]) (void)hipEventDestroy(L.ev[k]);
+    if (L.joined) (void)hipEventDestroy(L.joined);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   delete ctx;
 }

@@ -167,6 +167,29 @@ def test_pipelines_agree_on_recipes(gpu_ctx, recipe):
     scene.close()
 
 
+def test_parallel_pipelines_trace_the_same_paths(gpu_ctx, monkeypatch):
+    """A render call may be split by sample index between several wavefront pipelines that run side by side on
+    streams of their own (RTX_WF_LANES; by default large calls use up to four).  Paths are addressed by (pixel,
+    sample), so the split changes nothing but the order of the additions; the workspace grows when a later call
+    needs more paths in flight."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("cornell", gp, width=64, spp=25, depth=12)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    out = {}
+    for lanes, cap in (("1", "4096"), ("3", "1024"), ("4", "65536"), ("8", "2048")):
+        monkeypatch.setenv("RTX_WF_LANES", lanes)
+        monkeypatch.setenv("RTX_WF_CAPACITY", cap)
+        gpu_ctx.reset_stats()
+        out[lanes] = (scene.render(cam, rt.render_opts(cam, seed=21, pipeline=_capi.PIPELINE_WAVEFRONT)), gpu_ctx.stats())
+    base, sbase = out["1"]
+    assert sbase["paths"] == 64 * 64 * 25 and base.sum() > 0
+    for lanes in ("3", "4", "8"):
+        img, st = out[lanes]
+        assert st["paths"] == sbase["paths"] and st["segments"] == sbase["segments"] and st["pdf_probes"] == sbase["pdf_probes"]
+        np.testing.assert_allclose(img, base, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 def test_sample_ranges_and_rectangles_add_up(gpu_ctx):
     """Sharding property: disjoint sample ranges and pixel rectangles sum to the full render (RNG streams are keyed
     by (pixel, sample), so the shards trace exactly the same paths)."""
