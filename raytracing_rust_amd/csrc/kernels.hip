@@ -843,19 +843,21 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
   // defer buffers; the deferred section's own program
   const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
-  // Stream walks (k_wf_stream) of the head and of the deferred section.  Measured: a section whose program sits in LDS
-  // is walked faster per ray inside the world-program kernel (its box loops leave issue slots that the waves in
-  // sphere and medium code use; on the final scene the streamed form is 6 % slower over all), a section walked from
-  // global memory is latency bound and gains from refilled lanes (stress scene: +34 %).  So a section is streamed when
-  // it does not fit LDS; RTX_WF_STREAM=1 streams every section, RTX_WF_STREAM=0 none.
+  // Stream walks (k_wf_stream) of the head and of the deferred section.  Measured: with ONE pipeline a section whose
+  // program sits in LDS is walked faster per ray inside the world-program kernel (its box loops leave issue slots
+  // that the waves in sphere and medium code use: the streamed form is 6 % slower on the final scene), while a section
+  // walked from global memory is latency bound and gains from refilled lanes (stress scene: +34 %).  With three or
+  // more pipelines side by side the other pipelines' kernels fill those slots and streaming wins everywhere (final
+  // scene, 4 pipelines: 1371 -> 1459 Msamples/s).  So a section is streamed when it does not fit LDS or when at
+  // least three pipelines run; RTX_WF_STREAM=1 streams every section, 0 none, 2 only the head, 3 only the deferred.
   const char* stream_env = getenv("RTX_WF_STREAM");
   const int stream_mode = stream_env ? atoi(stream_env) : -1;  // -1: by size
   const size_t head_bytes = sc->dev.head_end ? (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 : 0;
   const bool head_lds = head_bytes <= kLdsBudget;
   const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
   const bool tail_lds = tail_bytes <= kLdsBudget;
-  const bool stream_head = sc->dev.head_end != 0 && (stream_mode == 1 || (stream_mode < 0 && !head_lds));
-  const bool stream_tail = tail_begin != 0 && (stream_mode == 1 || (stream_mode < 0 && !tail_lds));
+  const bool stream_head = sc->dev.head_end != 0 && (stream_mode == 1 || stream_mode == 2 || (stream_mode < 0 && (!head_lds || n_lanes >= 3)));
+  const bool stream_tail = tail_begin != 0 && (stream_mode == 1 || stream_mode == 3 || (stream_mode < 0 && (!tail_lds || n_lanes >= 3)));
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   Scene dev = sc->dev;
   dev.head_end = head_end;
