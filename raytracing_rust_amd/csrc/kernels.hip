@@ -809,10 +809,11 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
 // A large call is split by sample index between up to four such pipelines, one on the caller's stream and the others
 // on streams of the library (forked from and joined to the caller's stream with events): each kernel of an iteration
 // depends on the one before it, so a single pipeline leaves CUs idle while every launch drains; independent pipelines
-// fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s): 1 pipeline of 8 M paths in
-// flight 1198, of 32 M 1305; 2 x 8 M 1268; 4 x 8 M 1348; 4 x 16 M 1372; 4 x 32 M 1384.  Default: one pipeline per 4 M
-// camera paths of the call, at most four, each holding at most 16 M paths (3.7 GB) and no more than its share of the
-// call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
+// fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s, sections walked per ray): 1
+// pipeline of 8 M paths in flight 1198, of 32 M 1305; 2 x 8 M 1268; 4 x 8 M 1348; 4 x 16 M 1372; 4 x 32 M 1384; with
+// streamed sections 4 x 16 M 1487, 4 x 32 M 1524, 4 x 64 M 1536, 3 x 32 M 1489, 5 x 32 M 1454.  Default: one pipeline
+// per 4 M camera paths of the call, at most four, each holding at most 32 M paths (7.3 GB) and no more than its share
+// of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
   static unsigned v = 0;
   if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
@@ -827,7 +828,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const char* lanes_env = getenv("RTX_WF_LANES");
   const int want_lanes = lanes_env ? atoi(lanes_env) : (int)std::min<unsigned long long>(4ull, call_paths >> 22);
   const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
-  uint32_t cap = 1u << 24;
+  uint32_t cap = 1u << 25;
   if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
   {  // no more than a pipeline's share of the call needs (whole sample indices; at least 64 K)
     const unsigned long long share = per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes);
