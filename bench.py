@@ -21,17 +21,24 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
-# Algorithmic bytes per ray segment.  Traversal kernel (the dominant one): reads the ray (origin, direction, time:
-# 7 doubles) and, because the scene has media, the path's RNG address (pixel, sample, bounce: 3 u32); writes the hit
-# (t f64, kind_idx u32, ctx u32): 56 + 12 + 16 = 84 B.  A whole bounce adds the shading kernel's reads (ray 56 +
-# throughput 24 + ids 12 + hit 16 = 108 B) and its survivor record (80 + 12 = 92 B) or pixel atomics (24 B): ~300 B.
-TRAVERSE_BYTES = 84
-BOUNCE_BYTES = 300
-# HBM-side traffic of the world-program traversal kernel per segment, from rocprofv3 PMC passes over this command with
-# --rows 10 --steps 1 --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 54.83e9 B doubled (the
-# gfx950 half-count correction; it is calibrated for 16-byte loads and these are 8-byte ones, so an upper bound; the
-# ray reads alone are 72.7e9 B) + WRITE_SIZE 18.55e9 B (hit records: 17.1e9 B).
-TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 54.83e9 + 18.55e9) / 1.0699e9
+# Algorithmic bytes per ray segment.  World-program traversal kernel (k_wf_traverse<true,false,1>, the kernel with the
+# largest share of GPU time): reads the ray (origin, direction, time: 7 doubles), the path's RNG address because the
+# scene has media (pixel, sample, bounce: 3 u32) and the hit the head-section launch left (t f64, kind_idx u32, ctx
+# u32); writes the hit: 56 + 12 + 16 + 16 = 100 B (84 B when the head section is not walked separately).  A whole
+# bounce adds the head-section launch (ray 56 in, hit 16 out), the deferred-section launch (4 + 56 + 16 in, 16 out
+# for one ray in nine), the shading kernel's reads (ray 56 + throughput 24 + ids 12 + hit 16 = 108 B) and its survivor
+# record (80 + 12 = 92 B) or pixel atomics (24 B): about 390 B.
+TRAVERSE_BYTES = 100
+TRAVERSE_BYTES_UNSPLIT = 84
+BOUNCE_BYTES = 390
+# HBM-side traffic of that kernel per segment, from rocprofv3 PMC passes over this command with --rows 10 --steps 1
+# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 72.84e9 B doubled (the gfx950 half-count
+# correction; it is calibrated for 16-byte loads and these are 8- and 4-byte ones, so an upper bound; the algorithmic
+# reads are 89.9e9 B) + WRITE_SIZE 18.39e9 B (hit records: 17.1e9 B).
+TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 72.84e9 + 18.39e9) / 1.0699e9
+# The same for the shading kernel: FETCH_SIZE 58.34e9 B doubled + WRITE_SIZE 67.30e9 B (algorithmic: 115.5e9 read,
+# 57.2e9 of survivor records + 10.8e9 of pixel atomics written).
+SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 58.34e9 + 67.30e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
 
 
@@ -138,13 +145,37 @@ def main():
     if rank == 0:
         assert bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
         assert paths == npix * rows * args.rows * args.steps * world_size
-        # HIP events around every k_wf_traverse launch, recorded by the library on the stream it launches on (rank 0)
+        # Device-side timing of every traversal / shading launch (the library takes the wall clock of the first block in
+        # and the last block out), rank 0.  The roofline entry is for whichever of the two took more GPU time.
         fused = st["traverse_launches"] == 0
-        n_launch = st["launches"] if fused else st["traverse_launches"]
-        kernel_ms = (st["render_ms"] if fused else st["traverse_ms"]) / max(1, n_launch)
-        seg_per_launch = st["segments"] / max(1, n_launch)
-        seg_bytes = BOUNCE_BYTES if fused else TRAVERSE_BYTES
-        achieved = seg_per_launch * seg_bytes / (kernel_ms * 1e-3) / 1e9
+        p_survive = 1.0 - paths / max(1.0, segments)      # a path ends exactly once
+        shade_bytes = 108 + 92 * p_survive + 24 * (1.0 - p_survive)
+        cands = [("k_render_fused", st["render_ms"], st["launches"], BOUNCE_BYTES, None)] if fused else [
+            ("k_wf_traverse<true,false,1>", st["traverse_ms"], st["traverse_launches"],
+             TRAVERSE_BYTES if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT, TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
+            ("k_wf_shade", st["shade_ms"], st["shade_launches"], shade_bytes, SHADE_PMC_TRAFFIC_PER_SEGMENT)]
+        rl = []
+        for name, ms, n_launch, seg_bytes, pmc in cands:
+            kernel_ms = ms / max(1, n_launch)
+            seg_per_launch = st["segments"] / max(1, n_launch)
+            achieved = seg_per_launch * seg_bytes / (kernel_ms * 1e-3) / 1e9
+            rl.append({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": None if pmc is None else seg_per_launch * pmc,
+                       "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r1_pmc_summary.txt",
+                       "kernel": name, "kernel_ms": kernel_ms, "launches": n_launch, "segments_per_launch": seg_per_launch,
+                       "algorithmic_bytes_per_segment": seg_bytes, "algorithmic_bytes_per_launch": seg_per_launch * seg_bytes,
+                       "gpu_ms": ms})
+        rl.sort(key=lambda r: -r["gpu_ms"])
+        roofline = dict(rl[0])
+        roofline.update({
+            "kernel_ms_source": "wall clock of the first block in / last block out of every launch, taken on the device "
+                                "(a launch shares the GPU with the launches of the other pipelines)",
+            "whole_bounce": {"algorithmic_bytes_per_segment": BOUNCE_BYTES,
+                             "achieved": segments / world_size / dt * BOUNCE_BYTES / 1e9, "unit": "GB/s",
+                             "frac": segments / world_size / dt * BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS},
+            "other_kernels": rl[1:],
+            "note": "f64 VALU/latency-bound code; the HBM streams of rays, hits and path state are the only bytes it must move; "
+                    "four pipelines run side by side, so a launch does not have the GPU to itself"})
         out = {
             "metric": "Msamples/s (node) final scene 800x800", "value": paths / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -152,18 +183,11 @@ def main():
             "config": {"workload": f"final scene (final_scene.rs) 800x800, depth 75, step = one render call of {args.rows} of the "
                                    f"70 rows of the 4900-sample stratification = {npix * rows * args.rows / 1e6:.1f}M camera "
                                    "paths per GPU per step",
-                       "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator"},
+                       "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator",
+                       "pipelines_per_gpu": int(os.environ.get("RTX_WF_LANES", "4")),
+                       "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 25)))},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if fused else seg_per_launch * TRAVERSE_PMC_TRAFFIC_PER_SEGMENT,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r1_pmc_summary.txt",
-                         "kernel": "k_render_fused" if fused else "k_wf_traverse<true,false,1>", "kernel_ms": kernel_ms,
-                         "launches": n_launch, "segments_per_launch": seg_per_launch,
-                         "algorithmic_bytes_per_segment": seg_bytes,
-                         "algorithmic_bytes_per_launch": seg_per_launch * seg_bytes,
-                         "traverse_share_of_render_time": None if fused else st["traverse_ms"] / max(1e-9, st["render_ms"]),
-                         "note": "f64 VALU/latency-bound BVH walk out of LDS; HBM streams are the only bytes it must move"},
+            "roofline": roofline,
         }
         if world_size == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

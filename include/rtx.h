@@ -191,12 +191,15 @@ typedef struct rtx_stats { /* totals since context creation */
   double render_ms;      /* stream time of render calls (HIP events around each call) */
   uint64_t launches;     /* number of render calls */
   double last_kernel_ms; /* device time of the most recent render call */
-  double traverse_ms;    /* device time of the world-program traversal launches (wavefront pipeline, HIP events) */
+  double traverse_ms;    /* device time of the world-program traversal launches (wavefront pipeline): wall clock of the
+                          * first block in / last block out of every launch, summed */
   uint64_t traverse_launches;
   double tail_ms;        /* device time of the deferred-section traversal launches, when the program has one */
   uint64_t tail_launches;
   double head_ms;        /* device time of the head-section traversal launches, when the program has one */
   uint64_t head_launches;
+  double shade_ms;       /* device time of the shading launches, measured like traverse_ms */
+  uint64_t shade_launches;
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;

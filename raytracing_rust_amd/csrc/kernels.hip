@@ -90,10 +90,13 @@ struct WfCounters {
   // of the current launch; sum and number of the launches completed so far.  HIP events cannot time a kernel while
   // other pipelines share the GPU: they would include the wait for a free CU.
   unsigned long long k1_start, k1_end, k1_sum, k1_count;
+  unsigned long long sh_start, sh_end, sh_sum, sh_count;  // the same for the shading launches
 };
 __device__ __forceinline__ void wf_flush_timing(WfCounters* c) {  // one thread, between launches
   if (c->k1_end > c->k1_start) { c->k1_sum += c->k1_end - c->k1_start; c->k1_count += 1; }
   c->k1_start = ~0ull; c->k1_end = 0ull;
+  if (c->sh_end > c->sh_start) { c->sh_sum += c->sh_end - c->sh_start; c->sh_count += 1; }
+  c->sh_start = ~0ull; c->sh_end = 0ull;
 }
 struct WfFrame {       // what a path index means: (sample offset, pixel rank); pixels of the rectangle in 8x8 tiles
   int x0, y0, w, h, sample_begin;
@@ -105,6 +108,7 @@ __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
   c->next_path = 0; c->total_paths = total;
   c->k1_start = ~0ull; c->k1_end = 0ull; c->k1_sum = 0ull; c->k1_count = 0ull;
+  c->sh_start = ~0ull; c->sh_end = 0ull; c->sh_sum = 0ull; c->sh_count = 0ull;
 }
 
 // One thread: decide how many new camera paths top the queue up and flip the in/out roles.  New paths take the
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   const uint32_t n = c->n_in;
   uint32_t probes = 0;
   __shared__ uint32_t s_count[4], s_base, s_first;
+  if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
   // the queue is handed out dynamically, one workgroup's worth at a time: the trip count is the same for every thread
   // of a workgroup, and no workgroup is left with a long static share at the end of the launch
   for (;;) {
@@ -424,6 +429,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t wp = probes;
   for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
   if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
+  if (n != 0 && threadIdx.x == 0) atomicMax(&c->sh_end, (unsigned long long)wall_clock64());
 }
 
 // Tail of a render call.  Once no new camera paths are left and only a few survivors remain, an iteration of three
@@ -581,8 +587,8 @@ struct rtx_context {
   double wall_clock_khz = 100000.0;  // rate of wall_clock64()
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
-  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0;
-  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0;
+  double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0, shade_ms = 0.0;
+  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
   // wavefront workspace (allocated on first use, kept for the context's lifetime): up to two independent pipelines
@@ -939,6 +945,8 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
         if (r.done) {  // the traversal launches of this pipeline, timed on the device
           ctx->traverse_ms += (double)c.k1_sum / ctx->wall_clock_khz;
           ctx->traverse_launches += c.k1_count;
+          ctx->shade_ms += (double)c.sh_sum / ctx->wall_clock_khz;
+          ctx->shade_launches += c.sh_count;
         }
       }
       r.k += 1;
@@ -1161,6 +1169,7 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
   out->head_ms = ctx->head_ms; out->head_launches = ctx->head_launches;
+  out->shade_ms = ctx->shade_ms; out->shade_launches = ctx->shade_launches;
   return RTX_OK;
 }
 
@@ -1170,7 +1179,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)));
-  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0;
+  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0;
   return RTX_OK;
 }
 
