@@ -228,6 +228,14 @@ RT_HD double schlick(double cosine, double ratio) {
   return r0s + (1.0 - r0s) * b5;
 }
 
+// The roulette draw (camera.rs:228) of a Lambertian or isotropic hit: the first block of the bounce's shading
+// stream.  A function of the path's coordinates only, so the wavefront shading kernel can evaluate it ahead of
+// shade_bounce and drop the paths it ends.
+RT_HD double shade_roulette_draw(PathRng rng, uint32_t bounce) {
+  rng_stream(rng, bounce, RNG_DOMAIN_SHADE);
+  return rng_next(rng);
+}
+
 // Everything ray_color does after world.hit returned (camera.rs:180-246).  Returns true when the path goes on
 // with `next`; false when it ended (ps.L is final).  A hit of kind NONE is a miss (camera.rs:179-181).
 RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, const Ray& wray,
@@ -284,6 +292,12 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
 
   // LAMBERTIAN (lambertian.rs:31-46) or ISOTROPIC (isotropic.rs:31-43)
   const bool lambert = m.kind == RTX_MAT_LAMBERTIAN;
+  // Russian roulette (camera.rs:227-231) is decided FIRST.  The reference draws it after the direction and the pdf
+  // check, but a path it ends returns the hit's emission either way, which is zero for these two materials
+  // (material.rs:59-61), and the draw is independent of everything else: the estimator is the same, and a path that
+  // is going to be ended skips the texture, the sampling and the light probes.
+  if (ps.depth > 3 && shade_roulette_draw(ps.rng, ps.bounce) > 0.8) return false;
+  ps.rng.n = 1;
   RT_SPROF(15);
   V3 atten = texture_value(S, m.tex, sf.u, sf.v, sf.p);
   RT_SPROF(7);
@@ -327,10 +341,7 @@ RT_HD bool shade_bounce(const Scene& S, const V3& background, bool use_lights, c
   }
 
   V3 f = atten * spdf;
-  if (ps.depth > 3) {                                // camera.rs:227-240
-    if (rng_next(ps.rng) > 0.8) return false;
-    f = f * (1.0 / 0.8);
-  }
+  if (ps.depth > 3) f = f * (1.0 / 0.8);             // camera.rs:232-240 (the roulette itself was decided above)
   ps.T = cmul(ps.T, f / pdf_value);
   next.o = sf.p; next.d = dir; next.tm = wray.tm;   // camera.rs:223
   ps.depth -= 1; ps.bounce += 1;

@@ -46,6 +46,20 @@ __shared__ unsigned long long g_prof_lds[16 * 30];
   } while (0)
 #endif
 #endif
+#if defined(RT_PROF) && defined(__HIP_DEVICE_COMPILE__)
+// tuning build: cycles of a phase of the shading kernel, per wave, one block in eight
+#define RT_KPROF_T(name) const long long name = clock64()
+#define RT_KPROF_ADD(slot, t0)                                                                        \
+  do {                                                                                                \
+    if ((blockIdx.x & 7u) == 0 && (threadIdx.x & 63u) == 0) {                                         \
+      atomicAdd(&g_sprof[(slot)], (unsigned long long)(clock64() - (t0)));                            \
+      atomicAdd(&g_sprof[16 + (slot)], 1ull);                                                         \
+    }                                                                                                 \
+  } while (0)
+#else
+#define RT_KPROF_T(name) do { } while (0)
+#define RT_KPROF_ADD(slot, t0) do { } while (0)
+#endif
 #include "core/rt_program.h"
 #include "core/rt_shade.h"
 
@@ -375,7 +389,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 #endif
 #define RT_SHADE_CHUNK (256u * RT_SHADE_PER_THREAD)  // entries a workgroup sorts and shades per trip
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
-#define RT_SHADE_KEYS 16u
+#define RT_SHADE_KEYS 16u         // material class | sphere << 3
+#ifndef RT_SHADE_DROP
+#define RT_SHADE_DROP 1
+#endif
 enum { MC_MISS = 0, MC_END = 1, MC_METAL = 2, MC_DIELECTRIC = 3, MC_LAMBERT = 4, MC_LAMBERT_IMAGE = 5, MC_LAMBERT_NOISE = 6, MC_ISOTROPIC = 7 };
 __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
                                                   int use_lights, WfCounters* c, WfQueue qin, WfHits h, WfQueue qout,
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t probes = 0;
   __shared__ uint32_t s_count[4], s_base, s_first;
 #if RT_SHADE_SORT
-  __shared__ uint32_t s_cnt[RT_SHADE_KEYS * RT_SHADE_SLOTS], s_key_base[RT_SHADE_KEYS], s_sorted[RT_SHADE_CHUNK];
+  __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
 #endif
   if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
   // the queue is handed out dynamically, one chunk at a time: the trip count is the same for every thread of a
@@ -400,19 +417,48 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   const uint32_t first = s_first;
   if (first >= n) break;
 #if RT_SHADE_SORT
-  const uint32_t chunk_n = n - first < RT_SHADE_CHUNK ? n - first : RT_SHADE_CHUNK;
+  RT_KPROF_T(kp_t0);
   uint32_t my_key[RT_SHADE_PER_THREAD], my_rank[RT_SHADE_PER_THREAD];
+  // Keys of this thread's entries.  Every step is written as a loop of its own over the entries, with unconditional
+  // loads from addresses that are always valid, so that the loads of a step are in flight together: one round trip
+  // per step instead of one per step and entry.
+  uint32_t c_kind[RT_SHADE_PER_THREAD], c_mat[RT_SHADE_PER_THREAD], c_db[RT_SHADE_PER_THREAD], c_px[RT_SHADE_PER_THREAD], c_sm[RT_SHADE_PER_THREAD];
+RT_UNROLL
+  for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    const uint32_t k = first + e * 256u + threadIdx.x, ks = k < n ? k : first;
+    c_kind[e] = h.kind_idx[ks];
+    if (RT_SHADE_DROP) { const uint32_t* u = qin.u + ks; c_px[e] = u[0]; c_sm[e] = u[(size_t)cap]; c_db[e] = u[2 * (size_t)cap]; }
+  }
+RT_UNROLL
+  for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    const uint32_t hkind = RTX_NODE_KIND(c_kind[e]), hidx = RTX_NODE_IDX(c_kind[e]);
+    const uint32_t* mp = &S.materials[0].kind;   // a miss reads something harmless
+    if (hkind == RTX_NODE_SPHERE) mp = &S.spheres[hidx].mat;
+    else if (hkind == RTX_NODE_QUAD) mp = &S.quads[hidx].mat;
+    else if (hkind == RTX_NODE_MEDIUM) mp = &S.media[hidx].mat;
+    c_mat[e] = *mp;
+  }
+RT_UNROLL
+  for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    const uint32_t hkind = RTX_NODE_KIND(c_kind[e]);
+    const bool hit = hkind == RTX_NODE_SPHERE || hkind == RTX_NODE_QUAD || hkind == RTX_NODE_MEDIUM;
+    const uint32_t cls = mat_class[hit ? c_mat[e] : 0u];
+    c_mat[e] = hit ? (cls | (hkind == RTX_NODE_SPHERE ? 8u : 0u)) : 0u;
+  }
+  // the roulette draw shade_bounce makes first for a Lambertian or isotropic hit: a path it ends contributes nothing
+  // (no emission) and is dropped here (drawn for every entry, without a branch: the eight draws overlap)
+  if (RT_SHADE_DROP) {
+RT_UNROLL
+    for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+      const double xi = shade_roulette_draw(rng_make(seed, c_px[e], c_sm[e]), c_db[e] & 0xFFFFu);
+      c_db[e] = ((c_mat[e] & 7u) >= MC_LAMBERT && (c_db[e] >> 16) > 3u && xi > 0.8) ? 1u : 0u;
+    }
+  }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
     const uint32_t k = first + e * 256u + threadIdx.x;
-    const bool valid = k < n;
-    uint32_t key = 0;
-    if (valid) {
-      const uint32_t kind_idx = h.kind_idx[k], hkind = RTX_NODE_KIND(kind_idx), hidx = RTX_NODE_IDX(kind_idx);
-      if (hkind == RTX_NODE_SPHERE) key = mat_class[S.spheres[hidx].mat] | 8u;
-      else if (hkind == RTX_NODE_QUAD) key = mat_class[S.quads[hidx].mat];
-      else if (hkind == RTX_NODE_MEDIUM) key = mat_class[S.media[hidx].mat];
-    }
+    const bool valid = k < n && !(RT_SHADE_DROP && c_db[e] != 0u);
+    const uint32_t key = c_mat[e];
     // stable rank among the entries of this wave with the same key: one ballot per key present in the wave
     const uint32_t v = e * 4u + wave;
     unsigned long long todo = __ballot(valid);
@@ -422,7 +468,7 @@ RT_UNROLL
       const uint32_t lk = __shfl(key, leader);
       const unsigned long long m = __ballot(valid && key == lk);
       if (key == lk) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if ((int)lane == leader) s_cnt[lk * RT_SHADE_SLOTS + v] = (uint32_t)__popcll(m);
+      if ((int)lane == leader) s_cnt[v * RT_SHADE_KEYS + lk] = (uint32_t)__popcll(m);
       todo &= ~m;
     }
     my_key[e] = valid ? key : 0xFFFFFFFFu; my_rank[e] = rank;
@@ -430,20 +476,24 @@ RT_UNROLL
   __syncthreads();
   if (threadIdx.x < RT_SHADE_KEYS) {  // exclusive prefix over the (wave, pass) slots of one key, and the key's total
     uint32_t run = 0;
-    for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) { const uint32_t x = s_cnt[threadIdx.x * RT_SHADE_SLOTS + v]; s_cnt[threadIdx.x * RT_SHADE_SLOTS + v] = run; run += x; }
+    for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) { const uint32_t x = s_cnt[v * RT_SHADE_KEYS + threadIdx.x]; s_cnt[v * RT_SHADE_KEYS + threadIdx.x] = run; run += x; }
     s_key_base[threadIdx.x] = run;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t run = 0;
     for (uint32_t k = 0; k < RT_SHADE_KEYS; ++k) { const uint32_t x = s_key_base[k]; s_key_base[k] = run; run += x; }
+    s_key_base[RT_SHADE_KEYS] = run;  // entries left to shade
   }
   __syncthreads();
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e)
-    if (my_key[e] != 0xFFFFFFFFu) s_sorted[s_key_base[my_key[e]] + s_cnt[my_key[e] * RT_SHADE_SLOTS + e * 4u + wave] + my_rank[e]] = first + e * 256u + threadIdx.x;
+    if (my_key[e] != 0xFFFFFFFFu) s_sorted[s_key_base[my_key[e]] + s_cnt[(e * 4u + wave) * RT_SHADE_KEYS + my_key[e]] + my_rank[e]] = first + e * 256u + threadIdx.x;
   __syncthreads();
+  const uint32_t chunk_n = s_key_base[RT_SHADE_KEYS];
+  RT_KPROF_ADD(12, kp_t0);
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD && e * 256u < chunk_n; ++e) {
+  RT_KPROF_T(kp_t1);
   const uint32_t pos = e * 256u + threadIdx.x;
   const bool have = pos < chunk_n;
   const uint32_t idx = have ? s_sorted[pos] : 0u;
@@ -499,6 +549,7 @@ RT_UNROLL
     u[0] = pixel; u[(size_t)cap] = sample; u[2 * (size_t)cap] = ((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu);
   }
   __syncthreads();  // s_count / s_base are reused by the next trip
+  RT_KPROF_ADD(13, kp_t1);
   }
   }
   // light-probe statistics: one atomic per wave

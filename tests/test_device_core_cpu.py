@@ -125,7 +125,10 @@ def test_resolve_bit_exact_vs_oracle():
 @pytest.mark.parametrize("name,width,samples", [("cornell", 40, 64), ("smoke", 40, 36), ("final", 48, 36)])
 def test_render_statistics_vs_oracle(name, width, samples):
     """Whole estimator (ray_color, camera.rs:167-247): the device core and the oracle use different RNGs, so images
-    agree in distribution: mean radiance within 3 %, per-path segment and light-probe counts within 3 %."""
+    agree in distribution: mean radiance within 3 %, per-path segment counts within 3 %.  Light probes: the device core
+    decides the roulette (camera.rs:227-231) before it samples a direction, so a path the roulette ends makes no probe
+    where the reference makes one and then drops the path: between 0.8 and 1 times the oracle's count (depth 20: the
+    last three bounces of a path have no roulette)."""
     go, gp = H.oracle_graph(), rt.Graph()
     wo, lo, cam = scenes.build(name, go, width=width, spp=samples, depth=20, prefix="orc_", lib=H.oracle_lib())
     wp, lp, _ = scenes.build(name, gp, width=width, spp=samples, depth=20)
@@ -135,7 +138,7 @@ def test_render_statistics_vs_oracle(name, width, samples):
     b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, sample_begin=0, sample_end=n, seed=4))
     assert ca["paths"] == cb["paths"] == cam.image_width * cam.image_height * n
     assert abs(ca["segments"] / cb["segments"] - 1) < 0.03
-    assert abs((ca["pdf_probes"] + 1) / (cb["pdf_probes"] + 1) - 1) < 0.03
+    assert 0.78 < (cb["pdf_probes"] + 1) / (ca["pdf_probes"] + 1) < 1.03
     assert np.isfinite(b).all()
     ma, mb = a.mean(axis=(0, 1)), b.mean(axis=(0, 1))
     assert np.abs(ma / mb - 1).max() < 0.03 + 0.3 / math.sqrt(n), (ma, mb)

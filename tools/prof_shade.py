@@ -13,6 +13,7 @@ from raytracing_rust_amd import _capi  # noqa: E402
 
 NAMES = {1: "miss", 2: "material record", 3: "resolve_hit", 4: "emission", 5: "metal", 6: "dielectric",
          7: "texture_value", 8: "direction sampling", 9: "pdf (lights)", 10: "throughput + roulette", 15: "(wait for other branches)"}
+PHASES = {12: "sort phase (per wave and trip)", 13: "shading pass (per wave and pass)"}
 
 
 def main():
@@ -32,10 +33,13 @@ def main():
     lib.rtx_debug_sprof_read(buf, 0)
     st = ctx.stats()
     wsegs = st["segments"] / 64.0 / 8.0          # one block in eight is measured
-    total = sum(buf[k] for k in range(15))
+    total = sum(buf[k] for k in range(12))
     print(f"{st['segments']} segments; {total / wsegs:.0f} accounted cycles per wave (without the wait bucket)")
     print(f"{'section':28s} {'share':>6s} {'waves that ran it':>18s} {'cycles each':>12s}")
-    for k in range(16):
+    for k in PHASES:
+        if buf[16 + k]:
+            print(f"{PHASES[k]:34s} {buf[16 + k]} times, {buf[k] / buf[16 + k]:10.0f} cycles each, {buf[k] / wsegs:10.0f} cycles per 64 segments")
+    for k in list(range(12)) + [15]:
         if buf[16 + k]:
             print(f"{NAMES.get(k, k):28s} {buf[k] / total:6.1%} {buf[16 + k] / wsegs:18.2f} {buf[k] / buf[16 + k]:12.0f}")
 
