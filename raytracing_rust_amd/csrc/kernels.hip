@@ -390,6 +390,9 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 #define RT_SHADE_CHUNK (256u * RT_SHADE_PER_THREAD)  // entries a workgroup sorts and shades per trip
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
 #define RT_SHADE_KEYS 16u         // material class | sphere << 3
+#ifndef RT_SHADE_LDS_TABLES
+#define RT_SHADE_LDS_TABLES 8192    // bytes of LDS for the small scene tables (0 = leave them in global memory)
+#endif
 #ifndef RT_SHADE_DROP
 #define RT_SHADE_DROP 1
 #endif
@@ -406,6 +409,32 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
 #endif
   if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
+#if RT_SHADE_LDS_TABLES
+  // Small material, texture, light and transform tables are staged in LDS: shade_bounce reaches them through chains
+  // of dependent loads (hit -> material -> texture, light -> its primitive), and with two waves per SIMD every
+  // round trip to the L2 shows.  The table pointers of this kernel's copy of the scene then point into LDS.
+  __shared__ __attribute__((aligned(16))) unsigned char s_tables[RT_SHADE_LDS_TABLES];
+  {
+    const uint32_t bm = S.n_materials * (uint32_t)sizeof(rtx_material), bt = S.n_textures * (uint32_t)sizeof(rtx_texture);
+    const uint32_t bl = S.n_lights * (uint32_t)sizeof(rtx_light), bx = S.n_xforms * (uint32_t)sizeof(rtx_xform), bo = S.n_xform_ops * (uint32_t)sizeof(rtx_xform_op);
+    if ((unsigned long long)bm + bt + bl + bx + bo <= RT_SHADE_LDS_TABLES && n != 0) {   // every size is a multiple of 8
+      const uint64_t* src[5] = {(const uint64_t*)S.materials, (const uint64_t*)S.textures, (const uint64_t*)S.lights, (const uint64_t*)S.xforms, (const uint64_t*)S.xform_ops};
+      const uint32_t bytes[5] = {bm, bt, bl, bx, bo};
+      uint32_t at = 0;
+      for (int t = 0; t < 5; ++t) {
+        uint64_t* dst = (uint64_t*)(s_tables + at);
+        for (uint32_t k = threadIdx.x; k < bytes[t] / 8u; k += 256u) dst[k] = src[t][k];
+        at += bytes[t];
+      }
+      S.materials = (const rtx_material*)s_tables;
+      S.textures = (const rtx_texture*)(s_tables + bm);
+      S.lights = (const rtx_light*)(s_tables + bm + bt);
+      S.xforms = (const rtx_xform*)(s_tables + bm + bt + bl);
+      S.xform_ops = (const rtx_xform_op*)(s_tables + bm + bt + bl + bx);
+      __syncthreads();
+    }
+  }
+#endif
   // the queue is handed out dynamically, one chunk at a time: the trip count is the same for every thread of a
   // workgroup, and no workgroup is left with a long static share at the end of the launch
   for (;;) {
