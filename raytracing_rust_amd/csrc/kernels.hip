@@ -241,6 +241,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     if (wbase >= n) break;
     seen = wbase;
   for (uint32_t pass = 0; pass < batch && wbase + pass < n; pass += 64u) {
+    RT_KPROF_T(kp_pass);
     const uint32_t k = wbase + pass + lane;
     const bool active = k < n;
     const uint32_t idx = TAIL ? defer_list[active ? k : 0] : (active ? k : 0);
@@ -262,10 +263,12 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       if (active && hit_any(hit)) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
     } else {
       const double t0 = behind_head ? h.t[idx] : RT_INF;
+      RT_KPROF_ADD(14, kp_pass);
       const uint32_t kind0 = behind_head ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind_head ? h.ctx[idx] : 0u;
       const bool deferred = walk_program<MM, true>(S, prog, behind_head ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
                                                    MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0);
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
+      RT_KPROF_ADD(11, kp_pass);
       if (collect) {
         const unsigned long long m = __ballot(active && deferred);
         if (active && deferred) wave_defer[n_wait + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
@@ -503,16 +506,24 @@ RT_UNROLL
     my_key[e] = valid ? key : 0xFFFFFFFFu; my_rank[e] = rank;
   }
   __syncthreads();
-  if (threadIdx.x < RT_SHADE_KEYS) {  // exclusive prefix over the (wave, pass) slots of one key, and the key's total
-    uint32_t run = 0;
-    for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) { const uint32_t x = s_cnt[v * RT_SHADE_KEYS + threadIdx.x]; s_cnt[v * RT_SHADE_KEYS + threadIdx.x] = run; run += x; }
-    s_key_base[threadIdx.x] = run;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < RT_SHADE_KEYS; ++k) { const uint32_t x = s_key_base[k]; s_key_base[k] = run; run += x; }
-    s_key_base[RT_SHADE_KEYS] = run;  // entries left to shade
+  if (wave == 0) {
+    // lane k < RT_SHADE_KEYS: exclusive prefix over the (wave, pass) slots of key k (all counts read first, so the LDS
+    // round trips overlap), then an exclusive prefix of the keys' totals across the lanes
+    uint32_t x[RT_SHADE_SLOTS], run = 0;
+    const uint32_t kk = lane < RT_SHADE_KEYS ? lane : 0u;
+RT_UNROLL
+    for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) x[v] = s_cnt[v * RT_SHADE_KEYS + kk];
+RT_UNROLL
+    for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) { const uint32_t c0 = x[v]; x[v] = run; run += c0; }
+    if (lane < RT_SHADE_KEYS) {
+RT_UNROLL
+      for (uint32_t v = 0; v < RT_SHADE_SLOTS; ++v) s_cnt[v * RT_SHADE_KEYS + kk] = x[v];
+    }
+    uint32_t incl = lane < RT_SHADE_KEYS ? run : 0u;
+RT_UNROLL
+    for (uint32_t off = 1; off < RT_SHADE_KEYS; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+    if (lane < RT_SHADE_KEYS) s_key_base[lane] = incl - run;
+    if (lane == RT_SHADE_KEYS - 1u) s_key_base[RT_SHADE_KEYS] = incl;  // entries left to shade
   }
   __syncthreads();
 RT_UNROLL

@@ -13,7 +13,8 @@ from raytracing_rust_amd import _capi  # noqa: E402
 
 NAMES = {1: "miss", 2: "material record", 3: "resolve_hit", 4: "emission", 5: "metal", 6: "dielectric",
          7: "texture_value", 8: "direction sampling", 9: "pdf (lights)", 10: "throughput + roulette", 15: "(wait for other branches)"}
-PHASES = {12: "sort phase (per wave and trip)", 13: "shading pass (per wave and pass)"}
+PHASES = {12: "sort phase (per wave and trip)", 13: "shading pass (per wave and pass)",
+          14: "traversal: pass start to walk start", 11: "traversal: pass start to hit stored"}
 
 
 def main():
@@ -41,7 +42,7 @@ def main():
             print(f"{PHASES[k]:34s} {buf[16 + k]} times, {buf[k] / buf[16 + k]:10.0f} cycles each, {buf[k] / wsegs:10.0f} cycles per 64 segments")
     for k in list(range(12)) + [15]:
         if buf[16 + k]:
-            print(f"{NAMES.get(k, k):28s} {buf[k] / total:6.1%} {buf[16 + k] / wsegs:18.2f} {buf[k] / buf[16 + k]:12.0f}")
+            print(f"{str(NAMES.get(k, k)):28s} {buf[k] / total:6.1%} {buf[16 + k] / wsegs:18.2f} {buf[k] / buf[16 + k]:12.0f}")
 
 
 if __name__ == "__main__":
