@@ -12,7 +12,8 @@
 //   ENTER/EXIT idx = transform context, aux = op count         payload ops x {kind, a, b, c}
 //   MEDIUM    idx = medium, aux = first unit of its boundary   payload {neg_inv_density, needs_uv}
 //   MEDIUM_S  idx = medium whose boundary is one static sphere payload {neg_inv_density, needs_uv, DSphere}
-//   SPHERE, QUAD (moving spheres, general quads): no payload, the walker reads the ABI tables
+//   SPHERE    idx = sphere (moving spheres)                    payload {c0[3], dc[3], radius}             (8 units)
+//   QUAD      (general quads): no payload, the walker reads the ABI table
 //   SYNC, NOP, END: no payload; an END closes the world program and every medium boundary program.
 //
 // Visiting order and skip links are those of the ABI program.  Static spheres and quads whose normal is an exact
@@ -251,6 +252,7 @@ struct CompiledProgram {
       case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * d.xforms[it.idx].n_ops;
       case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
       case PROG_NODE_MEDIUM_S: return PROG_MEDIUM_S_UNITS;
+      case RTX_NODE_SPHERE: return PROG_SPHERE_UNITS;
       default: return 1u;
     }
   }
@@ -355,6 +357,11 @@ struct CompiledProgram {
           const DSphere rec = {sp.c0[0], sp.c0[1], sp.c0[2], sp.radius};
           memcpy(u + 1 + PROG_SPHERE_S_UNITS * s, &rec, sizeof(rec));
         }
+      } else if (it.kind == RTX_NODE_SPHERE) {   // a general (moving) sphere carries its record inline
+        const rtx_sphere& sp = d.spheres[it.idx];
+        u[0] = (uint64_t)d.nodes[it.node].kind_idx;
+        const double rec[7] = {sp.c0[0], sp.c0[1], sp.c0[2], sp.dc[0], sp.dc[1], sp.dc[2], sp.radius};
+        memcpy(u + 1, rec, sizeof(rec));
       } else if (it.kind == PROG_NODE_QUAD_AA) {
         u[0] = (uint64_t)RTX_NODE_MAKE(it.kind, it.idx) | ((uint64_t)it.count << 32);
         for (uint32_t s = 0; s < it.count; ++s) memcpy(u + 1 + PROG_QUAD_AA_UNITS * s, &daaquads[it.idx + s], sizeof(DAAQuad));

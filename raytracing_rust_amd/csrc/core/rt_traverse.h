@@ -67,6 +67,7 @@ struct Scene : rtx_scene_desc {
 #define PROG_XFORM_OP_UNITS 4u   // per transform op of an ENTER/EXIT record: kind, a, b, c
 #define PROG_MEDIUM_UNITS 3u     // header, neg_inv_density, needs_uv
 #define PROG_MEDIUM_S_UNITS 7u   // header, neg_inv_density, needs_uv, DSphere of the boundary
+#define PROG_SPHERE_UNITS 8u     // a general (moving) sphere: header, c0[3], dc[3], radius
 #define PROG_NODE_NOP 6u         // filler
 #define PROG_NODE_END 7u         // end of a program (the world's, or a medium boundary's)
 #define PROG_NODE_SPHERE_S 8u    // run of static spheres, compact records (hits are reported as RTX_NODE_SPHERE)
@@ -87,6 +88,7 @@ RT_HD uint32_t prog_record_units(uint64_t unit) {
     case RTX_NODE_ENTER: case RTX_NODE_EXIT: return 1u + PROG_XFORM_OP_UNITS * aux;
     case RTX_NODE_MEDIUM: return PROG_MEDIUM_UNITS;
     case PROG_NODE_MEDIUM_S: return PROG_MEDIUM_S_UNITS;
+    case RTX_NODE_SPHERE: return PROG_SPHERE_UNITS;
     default: return 1u;
   }
 }
@@ -224,6 +226,26 @@ RT_HD bool sphere_hit_t(const rtx_sphere& s, const V3& o, const V3& d, double ti
   double a = norm2(d);
   double half_b = dot(oc, d);
   double c = norm2(oc) - s.radius * s.radius;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return false;
+  double sqrtd = sqrt(disc);
+  double root = (-half_b - sqrtd) / a;
+  if (!(tmin < root && root < tmax)) {
+    root = (-half_b + sqrtd) / a;
+    if (!(tmin < root && root < tmax)) return false;
+  }
+  t = root;
+  return true;
+}
+
+// Sphere::hit (sphere.rs:83-104) for a sphere given by the record a SPHERE unit carries: c0[3], dc[3], radius.  The
+// same operations on the same operands as sphere_hit_t over the table entry.
+RT_HD bool sphere_rec_hit_t(const double* rec, const V3& o, const V3& d, double time, double tmin, double tmax, double& t) {
+  V3 center = v3(rec[0], rec[1], rec[2]) + v3(rec[3], rec[4], rec[5]) * time;
+  V3 oc = o - center;
+  double a = norm2(d);
+  double half_b = dot(oc, d);
+  double c = norm2(oc) - rec[6] * rec[6];
   double disc = half_b * half_b - a * c;
   if (disc < 0.0) return false;
   double sqrtd = sqrt(disc);
@@ -423,8 +445,10 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
             mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
           }
         } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+          // in the world context the local ray IS the world ray: only a lane that stands in another context re-reads it
+          const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();
           cur = idx;
-          lr = lray_from_ops(prog + i + 1, count, rs.origin(), rs.dir());
+          lr = lray_from_ops(prog + i + 1, count, wo, wd);
           next = i + 1 + PROG_XFORM_OP_UNITS * count;
         } else if (MEDIA == MEDIA_ALL && kind == RTX_NODE_MEDIUM && use_media) {
           // save the enclosing query, run the boundary program from this context over the whole line
@@ -506,8 +530,8 @@ RT_UNROLL
       } else if (pick == CL_SPHERE) {
         if (running && cls == CL_SPHERE) {
           double t;
-          if (sphere_hit_t(S.spheres[idx], lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
-          next = i + 1;
+          if (sphere_rec_hit_t((const double*)(prog + i + 1), lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
+          next = i + PROG_SPHERE_UNITS;
         }
       } else if (pick == CL_QUAD) {
         if (running && cls == CL_QUAD) {  // a general quad, or a compact run met by a ray with non-finite components
@@ -648,8 +672,9 @@ RT_HD void walk_stream(const Scene& S, const uint64_t* prog, uint32_t begin, Fee
     if (RT_WAVE_ANY(cls == CL_CHEAP)) {
       if (cls == CL_CHEAP) {
         if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+          const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();  // as in walk_program
           cur = idx;
-          lr = lray_from_ops(prog + i + 1, count, rs.origin(), rs.dir());
+          lr = lray_from_ops(prog + i + 1, count, wo, wd);
           next = i + 1 + PROG_XFORM_OP_UNITS * count;
         } else {
           next = i + prog_record_units(unit);  // filler (a section holds no media and no deferred part)
@@ -713,8 +738,8 @@ RT_UNROLL
       } else if (pick == CL_SPHERE) {
         if (cls == CL_SPHERE) {
           double t;
-          if (sphere_hit_t(S.spheres[idx], lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
-          next = i + 1;
+          if (sphere_rec_hit_t((const double*)(prog + i + 1), lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
+          next = i + PROG_SPHERE_UNITS;
         }
       } else if (pick == CL_QUAD) {
         if (cls == CL_QUAD) {
