@@ -26,19 +26,22 @@ WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
 # scene has media (pixel, sample, bounce: 3 u32) and the hit the head-section launch left (t f64, kind_idx u32, ctx
 # u32); writes the hit: 56 + 12 + 16 + 16 = 100 B (84 B when the head section is not walked separately).  A whole
 # bounce adds the head-section launch (ray 56 in, hit 16 out), the deferred-section launch (4 + 56 + 16 in, 16 out
-# for one ray in nine), the shading kernel's reads (ray 56 + throughput 24 + ids 12 + hit 16 = 108 B) and its survivor
-# record (80 + 12 = 92 B) or pixel atomics (24 B): about 390 B.
+# for one ray in nine), the shading kernel's reads (16 B for its sort, then ray 56 + throughput 24 + ids 12 + hit 16 =
+# 108 B unless the roulette ended the path) and its survivor record (80 + 12 = 92 B) or pixel atomics (24 B): about 390 B.
 TRAVERSE_BYTES = 100
 TRAVERSE_BYTES_UNSPLIT = 84
 BOUNCE_BYTES = 390
 # HBM-side traffic of that kernel per segment, from rocprofv3 PMC passes over this command with --rows 10 --steps 1
-# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 72.84e9 B doubled (the gfx950 half-count
+# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 53.45e9 B doubled (the gfx950 half-count
 # correction; it is calibrated for 16-byte loads and these are 8- and 4-byte ones, so an upper bound; the algorithmic
-# reads are 89.9e9 B) + WRITE_SIZE 18.39e9 B (hit records: 17.1e9 B).
-TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 72.84e9 + 18.39e9) / 1.0699e9
-# The same for the shading kernel: FETCH_SIZE 58.34e9 B doubled + WRITE_SIZE 67.30e9 B (algorithmic: 115.5e9 read,
-# 57.2e9 of survivor records + 10.8e9 of pixel atomics written).
-SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 58.34e9 + 67.30e9) / 1.0699e9
+# reads are 89.9e9 B) + WRITE_SIZE 18.38e9 B (hit records: 17.1e9 B).
+TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 53.45e9 + 18.38e9) / 1.0699e9
+# The same for the shading kernel: FETCH_SIZE 132.9e9 B doubled + WRITE_SIZE 67.96e9 B (algorithmic: about 113e9 read,
+# 57.2e9 of survivor records + up to 10.8e9 of pixel atomics written).  The reads exceed the algorithmic bytes because
+# the kernel shades each chunk of 2048 queue entries in sorted order: a 128-byte line of a queue array holds 16
+# entries that are shaded by different waves at different times, and the chunks in flight (208 KB each, two per CU)
+# outgrow the 4 MB L2 of an XCD, so lines come back from the Infinity Cache, which these counters count.
+SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 132.9e9 + 67.96e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
 
 
@@ -148,8 +151,12 @@ def main():
         # Device-side timing of every traversal / shading launch (the library takes the wall clock of the first block in
         # and the last block out), rank 0.  The roofline entry is for whichever of the two took more GPU time.
         fused = st["traverse_launches"] == 0
-        p_survive = 1.0 - paths / max(1.0, segments)      # a path ends exactly once
-        shade_bytes = 108 + 92 * p_survive + 24 * (1.0 - p_survive)
+        # Shading kernel, per queue entry: the sort reads the hit kind and the path's coordinates (4 + 12 B); an entry
+        # the roulette does not end there is read in full (ray 56 + throughput 24 + ids 12 + hit 16 = 108 B) and then
+        # either written back as a survivor (92 B) or ends with three pixel atomics (24 B).  A path ends exactly once.
+        p_survive = 1.0 - paths / max(1.0, segments)
+        p_drop = st.get("roulette_drops", 0) / max(1.0, st["segments"])
+        shade_bytes = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
         cands = [("k_render_fused", st["render_ms"], st["launches"], BOUNCE_BYTES, None)] if fused else [
             ("k_wf_traverse<true,false,1>", st["traverse_ms"], st["traverse_launches"],
              TRAVERSE_BYTES if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT, TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
@@ -185,7 +192,7 @@ def main():
                                    "paths per GPU per step",
                        "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator",
                        "pipelines_per_gpu": int(os.environ.get("RTX_WF_LANES", "4")),
-                       "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 25)))},
+                       "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 26)))},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
             "roofline": roofline,
         }

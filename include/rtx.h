@@ -200,6 +200,8 @@ typedef struct rtx_stats { /* totals since context creation */
   uint64_t head_launches;
   double shade_ms;       /* device time of the shading launches, measured like traverse_ms */
   uint64_t shade_launches;
+  uint64_t roulette_drops; /* wavefront pipeline: hits whose path the roulette (camera.rs:227-231) ended before shading;
+                            * the shading kernel reads only their hit kind and path coordinates */
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
                                                   const uint8_t* __restrict__ mat_class) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n = c->n_in;
-  uint32_t probes = 0;
+  uint32_t probes = 0, drops = 0;
   __shared__ uint32_t s_count[4], s_base, s_first;
 #if RT_SHADE_SORT
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
@@ -531,6 +531,7 @@ RT_UNROLL
     if (my_key[e] != 0xFFFFFFFFu) s_sorted[s_key_base[my_key[e]] + s_cnt[(e * 4u + wave) * RT_SHADE_KEYS + my_key[e]] + my_rank[e]] = first + e * 256u + threadIdx.x;
   __syncthreads();
   const uint32_t chunk_n = s_key_base[RT_SHADE_KEYS];
+  if (threadIdx.x == 0) drops += (n - first < RT_SHADE_CHUNK ? n - first : RT_SHADE_CHUNK) - chunk_n;
   RT_KPROF_ADD(12, kp_t0);
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD && e * 256u < chunk_n; ++e) {
   RT_KPROF_T(kp_t1);
@@ -596,6 +597,7 @@ RT_UNROLL
   uint32_t wp = probes;
   for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
   if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
+  if (drops) atomicAdd(&stats[3], (unsigned long long)drops);
   if (n != 0 && threadIdx.x == 0) atomicMax(&c->sh_end, (unsigned long long)wall_clock64());
 }
 
@@ -753,7 +755,7 @@ struct rtx_context {
   int n_cus = 256;
   double wall_clock_khz = 100000.0;  // rate of wall_clock64()
   std::string error;
-  unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes
+  unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes, roulette drops
   double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0, shade_ms = 0.0;
   uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
@@ -994,7 +996,8 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
 // fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s, sections walked per ray): 1
 // pipeline of 8 M paths in flight 1198, of 32 M 1305; 2 x 8 M 1268; 4 x 8 M 1348; 4 x 16 M 1372; 4 x 32 M 1384; with
 // streamed sections 4 x 16 M 1487, 4 x 32 M 1524, 4 x 64 M 1536, 3 x 32 M 1489, 5 x 32 M 1454.  Default: one pipeline
-// per 4 M camera paths of the call, at most four, each holding at most 32 M paths (7.3 GB) and no more than its share
+// per 4 M camera paths of the call, at most four, each holding at most 64 M paths (14.7 GB; measured again after the
+// shading kernel learned to sort: 4 x 16 M 1731, 4 x 32 M 1781, 4 x 64 M 1807, 3 x 32 M 1742, 5 x 32 M 1691) and no more than its share
 // of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
   static unsigned v = 0;
@@ -1010,7 +1013,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const char* lanes_env = getenv("RTX_WF_LANES");
   const int want_lanes = lanes_env ? atoi(lanes_env) : (int)std::min<unsigned long long>(4ull, call_paths >> 22);
   const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
-  uint32_t cap = 1u << 25;
+  uint32_t cap = 1u << 26;
   if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
   {  // no more than a pipeline's share of the call needs (whole sample indices; at least 64 K)
     const unsigned long long share = per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes);
@@ -1154,8 +1157,8 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
   rtx_context* ctx = new rtx_context();
   ctx->device = dev;
   hipDeviceProp_t prop;
-  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     delete ctx;
     return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
   }
@@ -1352,9 +1355,9 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  unsigned long long c[3] = {0, 0, 0};
+  unsigned long long c[4] = {0, 0, 0, 0};
   HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-  out->paths = c[0]; out->segments = c[1]; out->pdf_probes = c[2];
+  out->paths = c[0]; out->segments = c[1]; out->pdf_probes = c[2]; out->roulette_drops = c[3];
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
@@ -1368,7 +1371,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 3 * sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)));
   ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0;
   return RTX_OK;
 }
