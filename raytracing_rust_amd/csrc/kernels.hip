@@ -88,23 +88,29 @@ struct WfHits {        // output of the traversal kernel, input of the shading k
   uint32_t* ctx;       // transform context of the hit
   double* uv;          // [2*cap]: the stale record (u,v) of a medium hit whose phase texture reads them; rarely written
 };
+// Every counter that a whole launch hammers with atomics sits in a 128-byte line of its own: atomics on one line are
+// served one after the other by the L2, whatever word of the line they address, and at tens of millions per second
+// that queue, not the arithmetic, sets the pace of a launch (measured: one more atomic per 256 shaded entries on the
+// line of n_out tripled the duration of the shading launch).
 struct WfCounters {
   uint32_t n_in;        // paths in the queue the traversal/shading kernels read
-  uint32_t n_out;       // survivors appended to the other queue by the shading kernel
   uint32_t gen_count;   // camera paths to start in this iteration
   uint32_t gen_slot;    // queue slot of the first of them (they follow the survivors)
   uint32_t gen_sample;  // sample offset of the first new path
   uint32_t gen_rem;     // its pixel rank within that sample
   uint32_t finished;    // set by k_wf_finish: the survivors have been run to their end
-  uint32_t n_defer;     // rays of this iteration that entered the deferred section
-  uint32_t work_main, work_tail;  // next queue entry to hand out in the two traversal launches of this iteration
-  uint32_t work_shade, work_head; // the same for the shading launch and for the head-section launch
   unsigned long long next_path, total_paths;
+  alignas(128) uint32_t n_out;      // queue slots the shading kernel has given to (possible) survivors
+  alignas(128) uint32_t n_defer;    // rays of this iteration that entered the deferred section
+  alignas(128) uint32_t work_main;  // next queue entry to hand out in the world-program traversal launch
+  alignas(128) uint32_t work_tail;  // ... in the deferred-section launch
+  alignas(128) uint32_t work_shade; // ... in the shading launch
+  alignas(128) uint32_t work_head;  // ... in the head-section launch
   // Device-side timing of the world-program traversal launches (wall_clock64 ticks): first block in, last block out
   // of the current launch; sum and number of the launches completed so far.  HIP events cannot time a kernel while
   // other pipelines share the GPU: they would include the wait for a free CU.
-  unsigned long long k1_start, k1_end, k1_sum, k1_count;
-  unsigned long long sh_start, sh_end, sh_sum, sh_count;  // the same for the shading launches
+  alignas(128) unsigned long long k1_start, k1_end, k1_sum, k1_count;
+  alignas(128) unsigned long long sh_start, sh_end, sh_sum, sh_count;  // the same for the shading launches
 };
 __device__ __forceinline__ void wf_flush_timing(WfCounters* c) {  // one thread, between launches
   if (c->k1_end > c->k1_start) { c->k1_sum += c->k1_end - c->k1_start; c->k1_count += 1; }
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 // list, densely packed, starting from the hit found so far.  Together the two are the undivided walk.
 #define RT_DEFER_SLOTS 128u  // per wave: up to 63 waiting entries + 64 new ones
 #ifndef RT_WAVE_BATCH
-#define RT_WAVE_BATCH 128u   // most queue entries a wave takes per atomic (a multiple of 64)
+#define RT_WAVE_BATCH 512u   // most queue entries a wave takes per atomic (a multiple of 64; measured on the final
+                             // scene: 128: 1793, 256: 1900, 512: 1913, 1024: 1909 Msamples/s)
 #endif
 //
 // MM (MEDIA_NONE / MEDIA_SPHERES / MEDIA_ALL) is what the world program needs for its media: a program without
@@ -325,7 +332,7 @@ struct QueueFeed {
   __device__ bool take(bool want, uint32_t& id) {
     if (wnext >= wend) {
       uint32_t batch = ((n - seen) / (2u * n_waves)) & ~63u;
-      batch = batch < 64u ? 64u : (batch > 4u * RT_WAVE_BATCH ? 4u * RT_WAVE_BATCH : batch);
+      batch = batch < 64u ? 64u : (batch > RT_WAVE_BATCH ? RT_WAVE_BATCH : batch);
       uint32_t b = 0;
       if (lane == 0) b = atomicAdd(work, batch);
       b = __shfl(b, 0);
@@ -375,26 +382,26 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 }
 
 // Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
-// ends adds throughput x radiance to its pixel; a path that goes on is appended to the other queue, compacted with
-// one ballot per wave and one atomic per workgroup, so dead lanes never reach the next traversal.
+// ends adds throughput x radiance to its pixel; a path that goes on is written to the other queue.
 //
-// The branches of shade_bounce differ a lot in cost (a miss or a light ends the path at once, a marble hit evaluates
-// seven octaves of noise), and a wave pays for every branch one of its lanes takes.  A workgroup therefore takes
-// RT_SHADE_CHUNK queue entries at a time and first sorts them by a key made of the hit material's class
+// Sorting.  The branches of shade_bounce differ a lot in cost (a miss or a light ends the path at once, a marble hit
+// evaluates seven octaves of noise), and a wave pays for every branch one of its lanes takes.  A workgroup therefore
+// takes RT_SHADE_CHUNK queue entries at a time and first sorts them by a key made of the hit material's class
 // (rtx_scene::mat_class) and the kind of primitive: a stable counting sort in LDS, ballots within each wave and a
 // small prefix over (key, wave).  Waves then shade runs of equal keys.  Paths are addressed by their own
 // coordinates (RNG included), so the order in which they are shaded changes no result.
-#ifndef RT_SHADE_SORT
-#define RT_SHADE_SORT 1
-#endif
-#ifndef RT_SHADE_PER_THREAD
+//
+// Queue slots.  The classes that always end a path (miss, light, NoMaterial) sort first; every other entry of the
+// chunk may go on, and the chunk takes that many slots of the other queue with ONE atomic (an atomic per 256-entry
+// pass on the counter's line is what used to bound this kernel).  The few entries that end after all (an absorbed
+// metal reflection, a rejected pdf, the last bounce) leave their slot as a DEAD entry: remaining depth 0 and a
+// harmless ray.  The traversal kernels walk a dead entry like any other; the next sort drops it.
 #define RT_SHADE_PER_THREAD 8u        // entries per thread and trip (measured: 4: 1646, 8: 1689, 16: 1705 Msamples/s)
-#endif
 #define RT_SHADE_CHUNK (256u * RT_SHADE_PER_THREAD)  // entries a workgroup sorts and shades per trip
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
-#define RT_SHADE_KEYS 16u         // material class | sphere << 3
+#define RT_SHADE_KEYS 16u             // material class << 1 | sphere
 #ifndef RT_SHADE_LDS_TABLES
-#define RT_SHADE_LDS_TABLES 8192    // bytes of LDS for the small scene tables (0 = leave them in global memory)
+#define RT_SHADE_LDS_TABLES 8192      // bytes of LDS for the small scene tables (0 = leave them in global memory)
 #endif
 #ifndef RT_SHADE_DROP
 #define RT_SHADE_DROP 1
@@ -406,11 +413,9 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
                                                   const uint8_t* __restrict__ mat_class) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n = c->n_in;
-  uint32_t probes = 0, drops = 0;
-  __shared__ uint32_t s_count[4], s_base, s_first;
-#if RT_SHADE_SORT
+  uint32_t probes = 0, drops = 0, dead = 0;
+  __shared__ uint32_t s_first, s_out_base;
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
-#endif
   if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
 #if RT_SHADE_LDS_TABLES
   // Small material, texture, light and transform tables are staged in LDS: shade_bounce reaches them through chains
@@ -441,14 +446,11 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   // the queue is handed out dynamically, one chunk at a time: the trip count is the same for every thread of a
   // workgroup, and no workgroup is left with a long static share at the end of the launch
   for (;;) {
-  if (threadIdx.x == 0) s_first = atomicAdd(&c->work_shade, RT_SHADE_SORT ? RT_SHADE_CHUNK : blockDim.x);
-#if RT_SHADE_SORT
+  if (threadIdx.x == 0) s_first = atomicAdd(&c->work_shade, RT_SHADE_CHUNK);
   for (uint32_t k = threadIdx.x; k < RT_SHADE_KEYS * RT_SHADE_SLOTS; k += 256u) s_cnt[k] = 0;
-#endif
   __syncthreads();
   const uint32_t first = s_first;
   if (first >= n) break;
-#if RT_SHADE_SORT
   RT_KPROF_T(kp_t0);
   uint32_t my_key[RT_SHADE_PER_THREAD], my_rank[RT_SHADE_PER_THREAD];
   // Keys of this thread's entries.  Every step is written as a loop of its own over the entries, with unconditional
@@ -459,7 +461,8 @@ RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
     const uint32_t k = first + e * 256u + threadIdx.x, ks = k < n ? k : first;
     c_kind[e] = h.kind_idx[ks];
-    if (RT_SHADE_DROP) { const uint32_t* u = qin.u + ks; c_px[e] = u[0]; c_sm[e] = u[(size_t)cap]; c_db[e] = u[2 * (size_t)cap]; }
+    const uint32_t* u = qin.u + ks;
+    c_px[e] = u[0]; c_sm[e] = u[(size_t)cap]; c_db[e] = u[2 * (size_t)cap];
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
@@ -475,21 +478,26 @@ RT_UNROLL
     const uint32_t hkind = RTX_NODE_KIND(c_kind[e]);
     const bool hit = hkind == RTX_NODE_SPHERE || hkind == RTX_NODE_QUAD || hkind == RTX_NODE_MEDIUM;
     const uint32_t cls = mat_class[hit ? c_mat[e] : 0u];
-    c_mat[e] = hit ? (cls | (hkind == RTX_NODE_SPHERE ? 8u : 0u)) : 0u;
+    c_mat[e] = hit ? ((cls << 1) | (hkind == RTX_NODE_SPHERE ? 1u : 0u)) : 0u;
   }
-  // the roulette draw shade_bounce makes first for a Lambertian or isotropic hit: a path it ends contributes nothing
-  // (no emission) and is dropped here (drawn for every entry, without a branch: the eight draws overlap)
-  if (RT_SHADE_DROP) {
+  // Entries that are not shaded: 1 = a dead entry (remaining depth 0, see above); 2 = a Lambertian or isotropic hit
+  // whose path the roulette ends.  shade_bounce makes that draw first for these materials; a path it ends
+  // contributes nothing (no emission) and is dropped here (drawn for every entry, without a branch: the draws overlap).
 RT_UNROLL
-    for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+  for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    const uint32_t depth = c_db[e] >> 16;
+    uint32_t skip = depth == 0u ? 1u : 0u;
+    if (RT_SHADE_DROP) {
       const double xi = shade_roulette_draw(rng_make(seed, c_px[e], c_sm[e]), c_db[e] & 0xFFFFu);
-      c_db[e] = ((c_mat[e] & 7u) >= MC_LAMBERT && (c_db[e] >> 16) > 3u && xi > 0.8) ? 1u : 0u;
+      if (skip == 0u && (c_mat[e] >> 1) >= MC_LAMBERT && depth > 3u && xi > 0.8) skip = 2u;
     }
+    c_db[e] = skip;
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
     const uint32_t k = first + e * 256u + threadIdx.x;
-    const bool valid = k < n && !(RT_SHADE_DROP && c_db[e] != 0u);
+    const bool valid = k < n && c_db[e] == 0u;
+    if (k < n) { dead += c_db[e] == 1u ? 1u : 0u; drops += c_db[e] == 2u ? 1u : 0u; }
     const uint32_t key = c_mat[e];
     // stable rank among the entries of this wave with the same key: one ballot per key present in the wave
     const uint32_t v = e * 4u + wave;
@@ -523,81 +531,68 @@ RT_UNROLL
 RT_UNROLL
     for (uint32_t off = 1; off < RT_SHADE_KEYS; off <<= 1) { const uint32_t y = __shfl_up(incl, off); if (lane >= off) incl += y; }
     if (lane < RT_SHADE_KEYS) s_key_base[lane] = incl - run;
-    if (lane == RT_SHADE_KEYS - 1u) s_key_base[RT_SHADE_KEYS] = incl;  // entries left to shade
+    // entries to shade, and the queue slots of those that may go on (keys from MC_METAL << 1 on): one atomic
+    const uint32_t total = __shfl(incl, RT_SHADE_KEYS - 1u), n_end = __shfl(incl, (MC_METAL << 1) - 1u);
+    if (lane == 0) {
+      s_key_base[RT_SHADE_KEYS] = total;
+      s_out_base = total > n_end ? atomicAdd(&c->n_out, total - n_end) : 0u;
+    }
   }
   __syncthreads();
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e)
     if (my_key[e] != 0xFFFFFFFFu) s_sorted[s_key_base[my_key[e]] + s_cnt[(e * 4u + wave) * RT_SHADE_KEYS + my_key[e]] + my_rank[e]] = first + e * 256u + threadIdx.x;
   __syncthreads();
-  const uint32_t chunk_n = s_key_base[RT_SHADE_KEYS];
-  if (threadIdx.x == 0) drops += (n - first < RT_SHADE_CHUNK ? n - first : RT_SHADE_CHUNK) - chunk_n;
+  const uint32_t chunk_n = s_key_base[RT_SHADE_KEYS], n_end = s_key_base[MC_METAL << 1], out_base = s_out_base;
   RT_KPROF_ADD(12, kp_t0);
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD && e * 256u < chunk_n; ++e) {
-  RT_KPROF_T(kp_t1);
-  const uint32_t pos = e * 256u + threadIdx.x;
-  const bool have = pos < chunk_n;
-  const uint32_t idx = have ? s_sorted[pos] : 0u;
-#else
-  {
-  const uint32_t idx = first + threadIdx.x;
-  const bool have = idx < n;
-#endif
-  bool alive = false;
-  PathState ps;
-  Ray next;
-  uint32_t pixel = 0, sample = 0;
-  if (have) {
-    const double* f = qin.f + idx;
-    Ray ray;
-    ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
-    ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
-    ray.tm = f[6 * (size_t)cap];
-    ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
-    ps.L = v3(0.0, 0.0, 0.0);
-    const uint32_t* u = qin.u + idx;
-    pixel = u[0]; sample = u[(size_t)cap];
-    const uint32_t db = u[2 * (size_t)cap];
-    ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
-    ps.rng = rng_make(seed, pixel, sample);
-    Hit hit;
-    hit.t = h.t[idx]; hit.kind_idx = h.kind_idx[idx]; hit.ctx = h.ctx[idx];
-    alive = shade_bounce(S, v3(cam.background), use_lights != 0, ray, hit, h.uv + 2 * (size_t)idx, ps, next, probes);
-    if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
-      double* a = accum + (size_t)pixel * 3;
-      unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
+    RT_KPROF_T(kp_t1);
+    const uint32_t pos = e * 256u + threadIdx.x;
+    if (pos < chunk_n) {
+      const uint32_t idx = s_sorted[pos];
+      PathState ps;
+      Ray next;
+      const double* f = qin.f + idx;
+      Ray ray;
+      ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
+      ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
+      ray.tm = f[6 * (size_t)cap];
+      ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
+      ps.L = v3(0.0, 0.0, 0.0);
+      const uint32_t* u = qin.u + idx;
+      const uint32_t pixel = u[0], sample = u[(size_t)cap], db = u[2 * (size_t)cap];
+      ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
+      ps.rng = rng_make(seed, pixel, sample);
+      Hit hit;
+      hit.t = h.t[idx]; hit.kind_idx = h.kind_idx[idx]; hit.ctx = h.ctx[idx];
+      next.o = v3(0.0, 0.0, 0.0); next.d = v3(0.0, 0.0, 1.0); next.tm = 0.0;
+      const bool alive = shade_bounce(S, v3(cam.background), use_lights != 0, ray, hit, h.uv + 2 * (size_t)idx, ps, next, probes);
+      if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
+        double* a = accum + (size_t)pixel * 3;
+        unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
+      }
+      if (pos >= n_end) {   // this entry owns a slot of the other queue: the path's next segment, or a dead entry
+        const uint32_t slot = out_base + (pos - n_end);
+        if (!alive) { next.o = v3(0.0, 0.0, 0.0); next.d = v3(0.0, 0.0, 1.0); next.tm = 0.0; ps.T = v3(0.0, 0.0, 0.0); }
+        double* g = qout.f + slot;
+        g[0 * (size_t)cap] = next.o.x; g[1 * (size_t)cap] = next.o.y; g[2 * (size_t)cap] = next.o.z;
+        g[3 * (size_t)cap] = next.d.x; g[4 * (size_t)cap] = next.d.y; g[5 * (size_t)cap] = next.d.z;
+        g[6 * (size_t)cap] = next.tm;
+        g[7 * (size_t)cap] = ps.T.x; g[8 * (size_t)cap] = ps.T.y; g[9 * (size_t)cap] = ps.T.z;
+        uint32_t* w = qout.u + slot;
+        w[0] = pixel; w[(size_t)cap] = sample;
+        w[2 * (size_t)cap] = alive ? (((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu)) : 0u;
+      }
     }
-  }
-  // compaction of the survivors: ballot per wave, one atomic per workgroup
-  const unsigned long long mask = __ballot(alive);
-  if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t total = s_count[0] + s_count[1] + s_count[2] + s_count[3];
-    s_base = total ? atomicAdd(&c->n_out, total) : 0u;
-  }
-  __syncthreads();
-  if (alive) {
-    uint32_t base = s_base;
-    for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
-    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    double* f = qout.f + slot;
-    f[0 * (size_t)cap] = next.o.x; f[1 * (size_t)cap] = next.o.y; f[2 * (size_t)cap] = next.o.z;
-    f[3 * (size_t)cap] = next.d.x; f[4 * (size_t)cap] = next.d.y; f[5 * (size_t)cap] = next.d.z;
-    f[6 * (size_t)cap] = next.tm;
-    f[7 * (size_t)cap] = ps.T.x; f[8 * (size_t)cap] = ps.T.y; f[9 * (size_t)cap] = ps.T.z;
-    uint32_t* u = qout.u + slot;
-    u[0] = pixel; u[(size_t)cap] = sample; u[2 * (size_t)cap] = ((uint32_t)ps.depth << 16) | (ps.bounce & 0xFFFFu);
-  }
-  __syncthreads();  // s_count / s_base are reused by the next trip
-  RT_KPROF_ADD(13, kp_t1);
+    RT_KPROF_ADD(13, kp_t1);
   }
   }
-  // light-probe statistics: one atomic per wave
-  uint32_t wp = probes;
-  for (int off = 32; off > 0; off >>= 1) wp += __shfl_down(wp, off);
+  // statistics: one atomic per wave and counter
+  uint32_t wp = probes, wd = drops, wx = dead;
+  for (int off = 32; off > 0; off >>= 1) { wp += __shfl_down(wp, off); wd += __shfl_down(wd, off); wx += __shfl_down(wx, off); }
   if (lane == 0 && wp) atomicAdd(&stats[2], (unsigned long long)wp);
-  if (drops) atomicAdd(&stats[3], (unsigned long long)drops);
+  if (lane == 0 && wd) atomicAdd(&stats[3], (unsigned long long)wd);
+  if (lane == 0 && wx) atomicAdd(&stats[4], (unsigned long long)wx);
   if (n != 0 && threadIdx.x == 0) atomicMax(&c->sh_end, (unsigned long long)wall_clock64());
 }
 
@@ -628,6 +623,7 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
   const uint32_t pixel = u[0], sample = u[(size_t)cap], db = u[2 * (size_t)cap];
   ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
   ps.rng = rng_make(seed, pixel, sample);
+  alive = alive && ps.depth > 0;   // a dead entry of the shading kernel
   uint32_t segs = 0, probes = 0;
   while (__any(alive)) {  // the wave leaves together: the traversal votes across all 64 lanes
     Hit hit;
@@ -755,7 +751,7 @@ struct rtx_context {
   int n_cus = 256;
   double wall_clock_khz = 100000.0;  // rate of wall_clock64()
   std::string error;
-  unsigned long long* d_counters = nullptr;  // paths, segments, pdf_probes, roulette drops
+  unsigned long long* d_counters = nullptr;  // paths, queue entries traversed, pdf_probes, roulette drops, dead entries among those traversed
   double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0, shade_ms = 0.0;
   uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
@@ -1157,8 +1153,8 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
   rtx_context* ctx = new rtx_context();
   ctx->device = dev;
   hipDeviceProp_t prop;
-  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 5 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, 5 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     delete ctx;
     return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
   }
@@ -1355,9 +1351,9 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  unsigned long long c[4] = {0, 0, 0, 0};
+  unsigned long long c[5] = {0, 0, 0, 0, 0};
   HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-  out->paths = c[0]; out->segments = c[1]; out->pdf_probes = c[2]; out->roulette_drops = c[3];
+  out->paths = c[0]; out->segments = c[1] - c[4]; out->pdf_probes = c[2]; out->roulette_drops = c[3];  // c[4]: dead entries the traversal walked
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
@@ -1371,7 +1367,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 4 * sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 5 * sizeof(unsigned long long)));
   ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0;
   return RTX_OK;
 }
