@@ -193,7 +193,13 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 // passes the section's root box is only noted: its queue index goes to the defer list (collected per wave in LDS,
 // flushed 64 at a time with one atomic).  TAIL = true then walks the section's own program for the rays of that
 // list, densely packed, starting from the hit found so far.  Together the two are the undivided walk.
-#define RT_DEFER_SLOTS 128u  // per wave: up to 63 waiting entries + 64 new ones
+#ifndef RT_FEED_BATCH
+#define RT_FEED_BATCH 512u   // the same for the waves of a stream walk
+#endif
+#ifndef RT_DEFER_FLUSH
+#define RT_DEFER_FLUSH 64u   // entries of the defer list a wave appends per atomic (a multiple of 64)
+#endif
+#define RT_DEFER_SLOTS (RT_DEFER_FLUSH + 64u)  // per wave: fewer than RT_DEFER_FLUSH waiting entries + 64 new ones
 #ifndef RT_WAVE_BATCH
 #define RT_WAVE_BATCH 512u   // most queue entries a wave takes per atomic (a multiple of 64; measured on the final
                              // scene: 128: 1793, 256: 1900, 512: 1913, 1024: 1909 Msamples/s)
@@ -281,16 +287,16 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
         if (active && deferred) wave_defer[n_wait + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
         n_wait += (uint32_t)__popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (n_wait >= 64u) {                                   // flush 64 entries with one atomic
+        if (n_wait >= RT_DEFER_FLUSH) {                        // flush RT_DEFER_FLUSH entries with one atomic
           uint32_t at = 0;
-          if (lane == 0) at = atomicAdd(&c->n_defer, 64u);
+          if (lane == 0) at = atomicAdd(&c->n_defer, RT_DEFER_FLUSH);
           at = __shfl(at, 0);
-          defer_list[at + lane] = wave_defer[lane];
-          const uint32_t rest = lane < n_wait - 64u ? wave_defer[64u + lane] : 0u;
+          for (uint32_t k = 0; k < RT_DEFER_FLUSH; k += 64u) defer_list[at + k + lane] = wave_defer[k + lane];
+          const uint32_t rest = lane < n_wait - RT_DEFER_FLUSH ? wave_defer[RT_DEFER_FLUSH + lane] : 0u;   // fewer than 64 are left
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          if (lane < n_wait - 64u) wave_defer[lane] = rest;
+          if (lane < n_wait - RT_DEFER_FLUSH) wave_defer[lane] = rest;
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          n_wait -= 64u;
+          n_wait -= RT_DEFER_FLUSH;
         }
       }
     }
@@ -332,7 +338,7 @@ struct QueueFeed {
   __device__ bool take(bool want, uint32_t& id) {
     if (wnext >= wend) {
       uint32_t batch = ((n - seen) / (2u * n_waves)) & ~63u;
-      batch = batch < 64u ? 64u : (batch > RT_WAVE_BATCH ? RT_WAVE_BATCH : batch);
+      batch = batch < 64u ? 64u : (batch > RT_FEED_BATCH ? RT_FEED_BATCH : batch);
       uint32_t b = 0;
       if (lane == 0) b = atomicAdd(work, batch);
       b = __shfl(b, 0);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 // chunk may go on, and the chunk takes that many slots of the other queue with ONE atomic (an atomic per 256-entry
 // pass on the counter's line is what used to bound this kernel).  The few entries that end after all (an absorbed
 // metal reflection, a rejected pdf, the last bounce) leave their slot as a DEAD entry: remaining depth 0 and a
-// harmless ray.  The traversal kernels walk a dead entry like any other; the next sort drops it.
+// ray that misses everything at once.  The traversal kernels walk a dead entry like any other; the next sort drops it.
 #define RT_SHADE_PER_THREAD 8u        // entries per thread and trip (measured: 4: 1646, 8: 1689, 16: 1705 Msamples/s)
 #define RT_SHADE_CHUNK (256u * RT_SHADE_PER_THREAD)  // entries a workgroup sorts and shades per trip
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t probes = 0, drops = 0, dead = 0;
   __shared__ uint32_t s_first, s_out_base;
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
+  __shared__ uint32_t s_kind[RT_SHADE_CHUNK];  // hit kind of the sorted entries: the shading pass starts its chain of dependent loads from LDS
   if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
 #if RT_SHADE_LDS_TABLES
   // Small material, texture, light and transform tables are staged in LDS: shade_bounce reaches them through chains
@@ -541,7 +548,11 @@ RT_UNROLL
   __syncthreads();
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e)
-    if (my_key[e] != 0xFFFFFFFFu) s_sorted[s_key_base[my_key[e]] + s_cnt[(e * 4u + wave) * RT_SHADE_KEYS + my_key[e]] + my_rank[e]] = first + e * 256u + threadIdx.x;
+    if (my_key[e] != 0xFFFFFFFFu) {
+      const uint32_t pos = s_key_base[my_key[e]] + s_cnt[(e * 4u + wave) * RT_SHADE_KEYS + my_key[e]] + my_rank[e];
+      s_sorted[pos] = first + e * 256u + threadIdx.x;
+      s_kind[pos] = c_kind[e];
+    }
   __syncthreads();
   const uint32_t chunk_n = s_key_base[RT_SHADE_KEYS], n_end = s_key_base[MC_METAL << 1], out_base = s_out_base;
   RT_KPROF_ADD(12, kp_t0);
@@ -564,8 +575,8 @@ RT_UNROLL
       ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
       ps.rng = rng_make(seed, pixel, sample);
       Hit hit;
-      hit.t = h.t[idx]; hit.kind_idx = h.kind_idx[idx]; hit.ctx = h.ctx[idx];
-      next.o = v3(0.0, 0.0, 0.0); next.d = v3(0.0, 0.0, 1.0); next.tm = 0.0;
+      hit.t = h.t[idx]; hit.kind_idx = s_kind[pos]; hit.ctx = h.ctx[idx];
+      next.o = v3(0.0, 0.0, 0.0); next.d = v3(1.0, 1.0, 1.0); next.tm = 0.0;
       const bool alive = shade_bounce(S, v3(cam.background), use_lights != 0, ray, hit, h.uv + 2 * (size_t)idx, ps, next, probes);
       if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
         double* a = accum + (size_t)pixel * 3;
@@ -573,7 +584,13 @@ RT_UNROLL
       }
       if (pos >= n_end) {   // this entry owns a slot of the other queue: the path's next segment, or a dead entry
         const uint32_t slot = out_base + (pos - n_end);
-        if (!alive) { next.o = v3(0.0, 0.0, 0.0); next.d = v3(0.0, 0.0, 1.0); next.tm = 0.0; ps.T = v3(0.0, 0.0, 0.0); }
+        if (!alive) {
+          // A dead entry's ray must be cheap to walk: it starts far outside any scene and points away from it, so the
+          // first box it meets rejects it and every top-level primitive misses (all roots and plane distances are
+          // about -1e30).  Not axis-parallel: Aabb::hit skips the axes a ray is parallel to (aabb.rs:142-144), and a
+          // ray that skips two axes passes a large part of a BVH.
+          next.o = v3(1e30, 1e30, 1e30); next.d = v3(1.0, 1.0, 1.0); next.tm = 0.0; ps.T = v3(0.0, 0.0, 0.0);
+        }
         double* g = qout.f + slot;
         g[0 * (size_t)cap] = next.o.x; g[1 * (size_t)cap] = next.o.y; g[2 * (size_t)cap] = next.o.z;
         g[3 * (size_t)cap] = next.d.x; g[4 * (size_t)cap] = next.d.y; g[5 * (size_t)cap] = next.d.z;
@@ -1025,21 +1042,19 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
   // defer buffers; the deferred section's own program
   const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
-  // Stream walks (k_wf_stream) of the head and of the deferred section.  Measured: with ONE pipeline a section whose
-  // program sits in LDS is walked faster per ray inside the world-program kernel (its box loops leave issue slots
-  // that the waves in sphere and medium code use: the streamed form is 6 % slower on the final scene), while a section
-  // walked from global memory is latency bound and gains from refilled lanes (stress scene: +34 %).  With three or
-  // more pipelines side by side the other pipelines' kernels fill those slots and streaming wins everywhere (final
-  // scene, 4 pipelines: 1371 -> 1459 Msamples/s).  So a section is streamed when it does not fit LDS or when at
-  // least three pipelines run; RTX_WF_STREAM=1 streams every section, 0 none, 2 only the head, 3 only the deferred.
+  // Stream walks (k_wf_stream) of the head and of the deferred section: lanes take the next ray as soon as theirs leaves
+  // the section.  Measured on the final scene: one pipeline 1827 Msamples/s streamed against 1523 with the sections
+  // walked per ray inside the world-program kernel, two pipelines 1906 against 1597; a section walked from global
+  // memory gains more (stress scene: +34 %).  So sections are streamed by default; RTX_WF_STREAM=0 streams none,
+  // 2 only the head, 3 only the deferred section.
   const char* stream_env = getenv("RTX_WF_STREAM");
   const int stream_mode = stream_env ? atoi(stream_env) : -1;  // -1: by size
   const size_t head_bytes = sc->dev.head_end ? (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 : 0;
   const bool head_lds = head_bytes <= kLdsBudget;
   const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
   const bool tail_lds = tail_bytes <= kLdsBudget;
-  const bool stream_head = sc->dev.head_end != 0 && (stream_mode == 1 || stream_mode == 2 || (stream_mode < 0 && (!head_lds || n_lanes >= 3)));
-  const bool stream_tail = tail_begin != 0 && (stream_mode == 1 || stream_mode == 3 || (stream_mode < 0 && (!tail_lds || n_lanes >= 3)));
+  const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
+  const bool stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   Scene dev = sc->dev;
   dev.head_end = head_end;

@@ -125,8 +125,8 @@ def test_wavefront_and_fused_pipelines_trace_the_same_paths(gpu_ctx, name, width
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
     """The head section of the world program (the ground BVH of the final scene) and the deferred section (its sphere
-    cluster) can be walked per ray or as streams with refilled lanes (RTX_WF_STREAM=0 / 1; by default the choice
-    follows the size of the section).  Either way the wavefront pipeline must trace the fused pipeline's paths."""
+    cluster) can be walked per ray or as streams with refilled lanes (RTX_WF_STREAM=0 / 1; streams are the
+    default).  Either way the wavefront pipeline must trace the fused pipeline's paths."""
     gp = rt.Graph()
     wp, lp, cam = scenes.build("final", gp, width=160, spp=16, depth=40)
     scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
