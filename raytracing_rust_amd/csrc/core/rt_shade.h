@@ -170,8 +170,8 @@ RT_HD double lights_pdf_value(const Scene& S, const V3& origin, const V3& dir, u
     if (L.kind != RTX_NODE_NONE) {
       V3 o = origin, d = dir;
       if (L.ctx != 0) { o = ctx_point_to_local(S, L.ctx, o); d = ctx_dir_to_local(S, L.ctx, d); }
-      if (L.kind == RTX_NODE_QUAD) pv = quad_pdf_value(S.quads[L.idx], o, d);
-      else pv = sphere_pdf_value(S.spheres[L.idx], o, d);
+      if (L.kind == RTX_NODE_QUAD) pv = quad_pdf_value(S.light_quads ? S.light_quads[i] : S.quads[L.idx], o, d);
+      else pv = sphere_pdf_value(S.light_spheres ? S.light_spheres[i] : S.spheres[L.idx], o, d);
       ++probes;
     }
     sum += L.weight * pv;
@@ -192,8 +192,8 @@ RT_HD V3 lights_random(const Scene& S, const V3& origin, PathRng& rng) {
   V3 o = origin;
   if (L.ctx != 0) o = ctx_point_to_local(S, L.ctx, o);
   V3 d;
-  if (L.kind == RTX_NODE_QUAD) d = quad_random(S.quads[L.idx], o, rng);
-  else if (L.kind == RTX_NODE_SPHERE) d = sphere_random(S.spheres[L.idx], o, rng);
+  if (L.kind == RTX_NODE_QUAD) d = quad_random(S.light_quads ? S.light_quads[pick] : S.quads[L.idx], o, rng);
+  else if (L.kind == RTX_NODE_SPHERE) d = sphere_random(S.light_spheres ? S.light_spheres[pick] : S.spheres[L.idx], o, rng);
   else d = v3(1.0, 0.0, 0.0);
   if (L.ctx != 0) d = ctx_dir_to_world(S, L.ctx, d);
   return d;

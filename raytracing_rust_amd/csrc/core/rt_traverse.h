@@ -58,6 +58,10 @@ struct Scene : rtx_scene_desc {
   uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
   uint32_t _pad_scene;
+  // optional copies of the lights' primitive records, indexed like `lights` (null: read quads[] / spheres[]); the
+  // wavefront shading kernel points them at LDS
+  const rtx_quad* light_quads;
+  const rtx_sphere* light_spheres;
 };
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]

@@ -446,6 +446,21 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
       S.lights = (const rtx_light*)(s_tables + bm + bt);
       S.xforms = (const rtx_xform*)(s_tables + bm + bt + bl);
       S.xform_ops = (const rtx_xform_op*)(s_tables + bm + bt + bl + bx);
+      // the lights' own primitive records (read twice per diffuse bounce: HittablePDF::generate and ::value)
+      const uint32_t used = bm + bt + bl + bx + bo;
+      const uint32_t bq = S.n_lights * (uint32_t)sizeof(rtx_quad), bs = S.n_lights * (uint32_t)sizeof(rtx_sphere);
+      if ((unsigned long long)used + bq + bs <= RT_SHADE_LDS_TABLES) {
+        uint64_t* lq = (uint64_t*)(s_tables + used);
+        uint64_t* ls = (uint64_t*)(s_tables + used + bq);
+        const uint32_t uq = (uint32_t)sizeof(rtx_quad) / 8u, us = (uint32_t)sizeof(rtx_sphere) / 8u;
+        for (uint32_t i = 0; i < S.n_lights; ++i) {
+          const rtx_light L = ((const rtx_light*)src[2])[i];   // from global memory: the LDS copy is not complete yet
+          if (L.kind == RTX_NODE_QUAD) { const uint64_t* q = (const uint64_t*)&S.quads[L.idx]; for (uint32_t k = threadIdx.x; k < uq; k += 256u) lq[i * uq + k] = q[k]; }
+          else if (L.kind == RTX_NODE_SPHERE) { const uint64_t* q = (const uint64_t*)&S.spheres[L.idx]; for (uint32_t k = threadIdx.x; k < us; k += 256u) ls[i * us + k] = q[k]; }
+        }
+        S.light_quads = (const rtx_quad*)lq;
+        S.light_spheres = (const rtx_sphere*)ls;
+      }
       __syncthreads();
     }
   }
@@ -1212,7 +1227,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev._pad_scene = 0;
+  sc->dev.head_end = prog.head_end; sc->dev._pad_scene = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
