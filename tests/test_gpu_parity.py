@@ -122,6 +122,27 @@ def test_wavefront_and_fused_pipelines_trace_the_same_paths(gpu_ctx, name, width
     scene.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 5])
+def test_shallow_paths_leave_dead_entries_that_change_nothing(gpu_ctx, depth):
+    """The wavefront shading kernel reserves a queue slot for every hit that may go on; a path that ends after all
+    (here mostly: its last allowed bounce, camera.rs:174-176) leaves a dead entry that the traversal kernels walk and
+    the next sort drops.  With depths this small most reserved slots end dead: counters and image must still be
+    those of the fused pipeline, and dead entries must not be counted as segments."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("final", gp, width=120, spp=9, depth=depth)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    out = {}
+    for pipe in (_capi.PIPELINE_FUSED, _capi.PIPELINE_WAVEFRONT):
+        gpu_ctx.reset_stats()
+        out[pipe] = (scene.render(cam, rt.render_opts(cam, seed=5, pipeline=pipe)), gpu_ctx.stats())
+    (a, sa), (b, sb) = out[_capi.PIPELINE_FUSED], out[_capi.PIPELINE_WAVEFRONT]
+    assert sa["paths"] == sb["paths"] == 120 * 120 * 9
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    assert sb["segments"] <= sb["paths"] * depth
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 @pytest.mark.parametrize("mode", ["0", "1"])
 def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
     """The head section of the world program (the ground BVH of the final scene) and the deferred section (its sphere
