@@ -245,6 +245,14 @@ rtx_status rtx_resolve_rgb8_device(rtx_context* ctx, const double* accum_dev, in
 rtx_status rtx_first_hit_aov(rtx_scene* scene, const double* rays, size_t n, double* t, double* normal,
                              uint32_t* prim_id, uint32_t* mat_id, uint8_t* front);
 
+/* Order in which BvhNode::from_slice (acceleration/bvh.rs:26-71) arranges n objects, computed on the GPU for all nodes
+ * of a tree level at once: per node the longest axis of the merged box (aabb.rs:77-89), a stable sort by the boxes'
+ * lower bound on that axis (bvh.rs:61-62,75-83), the split at span/2, and the two-object rule of bvh.rs:48-57.
+ * boxes: n x {lo[3], hi[3]} (an object without a box: lo = +inf, hi = -inf); order_out[k] = index of the object at
+ * leaf position k of the finished tree.  The shape of the tree follows from n alone, so this permutation IS the
+ * build; rtxh_bvh uses it for large lists once rtxh_session_set_context has given the session a context. */
+rtx_status rtx_bvh_leaf_order(rtx_context* ctx, uint32_t n, const double* boxes, uint32_t* order_out);
+
 rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out);
 rtx_status rtx_reset_stats(rtx_context* ctx);
 

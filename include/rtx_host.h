@@ -30,6 +30,10 @@ typedef struct rtxh_session rtxh_session;
 
 rtxh_session* rtxh_session_new(void);
 void rtxh_session_free(rtxh_session* s);
+/* Optional: lets rtxh_bvh sort lists of RTXH_GPU_BVH_MIN objects or more on the context's GPU (rtx_bvh_leaf_order);
+ * the tree is the one the host build makes.  ctx must outlive the session's rtxh_bvh calls; NULL detaches. */
+void rtxh_session_set_context(rtxh_session* s, rtx_context* ctx);
+#define RTXH_GPU_BVH_MIN 4096
 const char* rtxh_last_error(const rtxh_session* s);
 
 /* Textures */

@@ -128,11 +128,13 @@ SYMBOLS = {
     "rtx_resolve_rgb8": (C.c_int, [P, PD, C.c_int, C.c_int, C.c_int, C.POINTER(u8)]),
     "rtx_resolve_rgb8_device": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "rtx_first_hit_aov": (C.c_int, [P, PD, C.c_size_t, PD, PD, C.POINTER(u32), C.POINTER(u32), C.POINTER(u8)]),
+    "rtx_bvh_leaf_order": (C.c_int, [P, u32, PD, C.POINTER(u32)]),
     "rtx_get_stats": (C.c_int, [P, C.POINTER(Stats)]),
     "rtx_reset_stats": (C.c_int, [P]),
     # include/rtx_host.h
     "rtxh_session_new": (P, []),
     "rtxh_session_free": (None, [P]),
+    "rtxh_session_set_context": (None, [P, P]),
     "rtxh_last_error": (C.c_char_p, [P]),
     "rtxh_tex_solid": (C.c_int, [P, f64, f64, f64]),
     "rtxh_tex_checker": (C.c_int, [P, f64, C.c_int, C.c_int]),

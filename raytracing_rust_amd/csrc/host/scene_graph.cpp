@@ -88,6 +88,7 @@ struct rtxh_session {
   std::vector<Obj> objs;
   uint32_t next_prim = 0;
   std::string error;
+  rtx_context* ctx = nullptr;  // set: rtxh_bvh sorts large lists on this context's GPU
   // flatten outputs
   std::vector<rtx_node> nodes;
   std::vector<rtx_aabb> boxes;
@@ -178,6 +179,24 @@ static std::unique_ptr<BvhTree> build_bvh(const rtxh_session* s, const std::vect
     size_t mid = span / 2;
     n->left = build_bvh(s, sorted, 0, mid);
     n->right = build_bvh(s, sorted, mid, sorted.size());
+  }
+  return n;
+}
+
+// The tree BvhNode::from_slice builds, from the leaf order it ends with (rtx_bvh_leaf_order): the shape follows from
+// the span alone (bvh.rs:39-66), the sorts and the two-object comparison have been applied to `order` already.
+static std::unique_ptr<BvhTree> build_bvh_ordered(const rtxh_session* s, const std::vector<int>& order, size_t start, size_t end) {
+  std::unique_ptr<BvhTree> n(new BvhTree());
+  const size_t span = end - start;
+  if (span <= 2) {
+    for (size_t i = start; i < end; ++i) { Box b; if (obj_box(s, order[i], b)) n->bbox = n->bbox.merge(b); }
+    n->left_obj = order[start];
+    n->right_obj = order[end - 1];
+  } else {
+    const size_t mid = start + span / 2;
+    n->left = build_bvh_ordered(s, order, start, mid);
+    n->right = build_bvh_ordered(s, order, mid, end);
+    n->bbox = n->left->bbox.merge(n->right->bbox);   // min/max are exact: the merge of all objects' boxes in any order
   }
   return n;
 }
@@ -519,12 +538,32 @@ int rtxh_box(rtxh_session* s, const double* a, const double* b, int mat) {  // b
   rtxh_list_add(s, list, add_quad(s, q5, dx, dz, mat));    // bottom
   return list;
 }
+void rtxh_session_set_context(rtxh_session* s, rtx_context* ctx) { if (s) s->ctx = ctx; }
 int rtxh_bvh(rtxh_session* s, int list) {
   if (!s->ok_obj(list) || s->objs[(size_t)list].kind != K_LIST) return s->fail("bvh: not a list handle");
   if (s->objs[(size_t)list].children.empty()) return s->fail("bvh: empty list");  // the reference would index out of bounds
   Obj o;
   o.kind = K_BVH;
-  o.tree = build_bvh(s, s->objs[(size_t)list].children, 0, s->objs[(size_t)list].children.size());
+  const std::vector<int>& children = s->objs[(size_t)list].children;
+  if (s->ctx && children.size() >= (size_t)RTXH_GPU_BVH_MIN) {
+    std::vector<double> boxes(children.size() * 6);
+    for (size_t i = 0; i < children.size(); ++i) {
+      Box b;
+      if (!obj_box(s, children[i], b)) b = Box();
+      double* o6 = &boxes[6 * i];
+      o6[0] = b.x.min; o6[1] = b.y.min; o6[2] = b.z.min; o6[3] = b.x.max; o6[4] = b.y.max; o6[5] = b.z.max;
+    }
+    std::vector<uint32_t> perm(children.size());
+    if (rtx_bvh_leaf_order(s->ctx, (uint32_t)children.size(), boxes.data(), perm.data()) != RTX_OK) {
+      s->error = std::string("bvh: GPU build failed: ") + rtx_last_error(s->ctx);
+      return -1;
+    }
+    std::vector<int> order(children.size());
+    for (size_t i = 0; i < children.size(); ++i) order[i] = children[perm[i]];
+    o.tree = build_bvh_ordered(s, order, 0, order.size());
+  } else {
+    o.tree = build_bvh(s, children, 0, children.size());
+  }
   o.has_box = true; o.box = o.tree->bbox;
   s->objs.push_back(std::move(o));
   return (int)s->objs.size() - 1;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rtx.h"
+#include "device_internal.h"
 
 #if defined(RT_PROF)
 // Tuning build only (make prof): cycles, trips and lanes per class of the traversal loop.  Wave leaders accumulate
@@ -818,6 +819,8 @@ static rtx_status fail(rtx_context* ctx, rtx_status st, const std::string& msg) 
   g_error = msg;
   return st;
 }
+int rtx_internal_device(const rtx_context* ctx) { return ctx->device; }
+rtx_status rtx_internal_fail(rtx_context* ctx, rtx_status st, const char* message) { return fail(ctx, st, message); }
 #define HIP_TRY(ctx, call)                                                                                  \
   do {                                                                                                      \
     hipError_t e_ = (call);                                                                                 \

@@ -46,6 +46,14 @@ class Graph:
         self.session = C.c_void_p(self.f["session_new"]())
         self._keep = []
 
+    def use_context(self, ctx):
+        """Let BvhNode of large lists be built on ctx's GPU (rtxh_session_set_context); None detaches.  The tree is the
+        one the host build makes."""
+        if self.prefix != "rtxh_":
+            raise GraphError("only the product's scene layer builds on a GPU")
+        self.lib.rtxh_session_set_context(self.session, ctx.handle if ctx is not None else None)
+        self._ctx = ctx
+
     def close(self):
         if self.session:
             self.f["session_free"](self.session)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--gpu-build", action="store_true", help="sort the BVH on the GPU (rtx_bvh_leaf_order)")
     args = ap.parse_args()
     import torch
     import raytracing_rust_amd as rt
@@ -32,6 +33,8 @@ def main():
         raise SystemExit("needs a GPU: the backend has no CPU path")
     ctx = rt.Context(0)
     g = rt.Graph()
+    if args.gpu_build:
+        g.use_context(ctx)
     t0 = time.perf_counter()
     world, lights, cam = rt.scenes.build("stress", g, width=args.width, depth=args.depth, n_prims=args.prims)
     t1 = time.perf_counter()
@@ -61,7 +64,7 @@ def main():
                     f"{args.samples} sample indices per step",
         "Msamples_per_s": st["paths"] / dt / 1e6, "Msegments_per_s": st["segments"] / dt / 1e6,
         "segments_per_path": st["segments"] / max(1, st["paths"]), "ms_per_step": dt / args.steps * 1e3,
-        "scene_build_s": t1 - t0, "flatten_compile_upload_s": t2 - t1,
+        "scene_build_s": t1 - t0, "bvh_built_on": "gpu" if args.gpu_build else "host", "flatten_compile_upload_s": t2 - t1,
         "traverse_ms_per_launch": st["traverse_ms"] / max(1, st["traverse_launches"]),
         "traverse_share_of_render_time": st["traverse_ms"] / max(1e-9, st["render_ms"]),
         "mean_radiance": float(accum.mean()) / ((args.steps + 1) * args.samples)}), flush=True)
