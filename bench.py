@@ -38,8 +38,8 @@ BOUNCE_BYTES = 390
 TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 53.66e9 + 18.07e9) / 1.0699e9
 # The same for the shading kernel: FETCH_SIZE 120.1e9 B doubled + WRITE_SIZE 68.69e9 B (algorithmic: about 113e9 read,
 # 57.2e9 of survivor records and dead entries + up to 10.8e9 of pixel atomics written).  The reads exceed the algorithmic bytes because
-# the kernel shades each chunk of 2048 queue entries in sorted order: a 128-byte line of a queue array holds 16
-# entries that are shaded by different waves at different times, and the chunks in flight (208 KB each, two per CU)
+# the kernel shades each chunk of 4096 queue entries in sorted order: a 128-byte line of a queue array holds 16
+# entries that are shaded by different waves at different times, and the chunks in flight (416 KB each, two per CU)
 # outgrow the 4 MB L2 of an XCD, so lines come back from the Infinity Cache, which these counters count.
 SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 120.1e9 + 68.69e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
