@@ -789,7 +789,7 @@ struct rtx_context {
   uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
-  // wavefront workspace (allocated on first use, kept for the context's lifetime): up to two independent pipelines
+  // wavefront workspace (allocated on first use, kept for the context's lifetime): up to RT_WF_MAX_LANES independent pipelines
   bool wf_ready = false;
   struct WfLane {
     uint32_t cap = 0;              // paths in flight its buffers hold
@@ -1024,11 +1024,9 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
 // A large call is split by sample index between up to four such pipelines, one on the caller's stream and the others
 // on streams of the library (forked from and joined to the caller's stream with events): each kernel of an iteration
 // depends on the one before it, so a single pipeline leaves CUs idle while every launch drains; independent pipelines
-// fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s, sections walked per ray): 1
-// pipeline of 8 M paths in flight 1198, of 32 M 1305; 2 x 8 M 1268; 4 x 8 M 1348; 4 x 16 M 1372; 4 x 32 M 1384; with
-// streamed sections 4 x 16 M 1487, 4 x 32 M 1524, 4 x 64 M 1536, 3 x 32 M 1489, 5 x 32 M 1454.  Default: one pipeline
-// per 4 M camera paths of the call, at most four, each holding at most 64 M paths (14.7 GB; measured again after the
-// shading kernel learned to sort: 4 x 16 M 1731, 4 x 32 M 1781, 4 x 64 M 1807, 3 x 32 M 1742, 5 x 32 M 1691) and no more than its share
+// fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s): 1 pipeline 1928, 2: 1906,
+// 3 x 32 M paths in flight 1960, 4 x 16 M 1731, 4 x 32 M 1933, 4 x 64 M 2058, 5: 1691, 6: 1675.  Default: one pipeline per
+// 4 M camera paths of the call, at most four, each holding at most 64 M paths (14.7 GB) and no more than its share
 // of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
   static unsigned v = 0;
@@ -1162,7 +1160,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       if (ctx->pending.size() > 2048) drain_events(ctx);
     }
   }
-  // the caller's stream continues when both pipelines are through
+  // the caller's stream continues when every pipeline is through
   for (int l = 1; l < n_lanes; ++l) {
     HIP_TRY(ctx, hipEventRecord(runs[l].L->joined, runs[l].s));
     HIP_TRY(ctx, hipStreamWaitEvent(stream, runs[l].L->joined, 0));
