@@ -114,10 +114,18 @@ RT_HD uint32_t prog_record_units(uint64_t unit) {
 #define RT_WAVE_ANY(p) (__ballot(p) != 0ull)
 #define RT_WAVE_COUNT(p) ((int)__popcll(__ballot(p)))
 #define RT_WAVE_LANES 64
+// Do all lanes with `on` hold the same value of v (at least one lane has `on`)?  first = that value.
+__device__ __forceinline__ bool rt_wave_uniform(bool on, int v, int& first, int& n_on) {
+  const unsigned long long m = __ballot(on);
+  first = __shfl(v, __ffsll((long long)m) - 1);
+  n_on = (int)__popcll(m);
+  return __ballot(on && v == first) == m;
+}
 #else
 #define RT_WAVE_ANY(p) (p)
 #define RT_WAVE_COUNT(p) ((p) ? 1 : 0)
 #define RT_WAVE_LANES 1
+inline bool rt_wave_uniform(bool, int v, int& first, int& n_on) { first = v; n_on = 1; return true; }
 #endif
 
 struct LRay {     // ray in the current transform context + per-axis reciprocals (aabb.rs:146)
@@ -469,20 +477,28 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
       RT_PROF_TRIP(CL_CHEAP);
     } else {
       // 3. every running lane stands on a primitive (or waits at a SYNC): run the class most lanes wait for
-      const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
-      const int n_s = RT_WAVE_COUNT(running && cls == CL_SPHERE), n_q = RT_WAVE_COUNT(running && cls == CL_QUAD);
-      const int n_m = RT_WAVE_COUNT(running && (cls == CL_MEDIUM_EVAL || cls == CL_MEDIUM_S)), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
-      const int n_x = RT_WAVE_COUNT(running && cls == CL_BOX);
-      int pick = CL_SYNC, best_n = 0;
-      if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
-      if (n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
-      if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
-      if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
-      if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
-      if (n_m > best_n) { pick = CL_MEDIUM_EVAL; best_n = n_m; }
-      // Boxes wait until no lane stands on a primitive, then every lane walks its boxes together: two alternating
-      // phases, so that a box trip serves as many lanes as possible.
-      if (best_n == 0 && n_x > 0) pick = CL_BOX;
+      int pick = CL_SYNC, best_n = 0, cls0 = 0;
+      if (rt_wave_uniform(running, cls, cls0, best_n)) {
+        // all of them stand on the same class (the common case in the top-level part of a program, where the rays of
+        // a wave move in step): no count per class is needed; the vote below would pick the same
+        pick = cls0 == CL_MEDIUM_S ? CL_MEDIUM_EVAL : cls0;
+        if (pick == CL_BOX || pick == CL_SYNC) best_n = 0;
+      } else {
+        const int n_ss = RT_WAVE_COUNT(running && cls == CL_SPHERE_S), n_a = RT_WAVE_COUNT(running && cls == CL_QUAD_AA);
+        const int n_s = RT_WAVE_COUNT(running && cls == CL_SPHERE), n_q = RT_WAVE_COUNT(running && cls == CL_QUAD);
+        const int n_m = RT_WAVE_COUNT(running && (cls == CL_MEDIUM_EVAL || cls == CL_MEDIUM_S)), n_b = RT_WAVE_COUNT(running && cls == CL_BOX6);
+        const int n_x = RT_WAVE_COUNT(running && cls == CL_BOX);
+        best_n = 0;
+        if (n_ss > best_n) { pick = CL_SPHERE_S; best_n = n_ss; }
+        if (n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
+        if (n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+        if (n_s > best_n) { pick = CL_SPHERE; best_n = n_s; }
+        if (n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
+        if (n_m > best_n) { pick = CL_MEDIUM_EVAL; best_n = n_m; }
+        // Boxes wait until no lane stands on a primitive, then every lane walks its boxes together: two alternating
+        // phases, so that a box trip serves as many lanes as possible.
+        if (best_n == 0 && n_x > 0) pick = CL_BOX;
+      }
       RT_PROF_LANES(pick == CL_BOX ? 0 : best_n);
       if (pick == CL_SYNC) {
         // 4. everybody waits at a SYNC: pass it together
@@ -591,7 +607,12 @@ RT_UNROLL
       }
       RT_PROF_TRIP(pick);
     }
-    if (running && next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
+    if (running && next != i) {
+      RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls);
+      i = next; unit = prog[i];
+      // the END of the outermost program ends the walk at once (no trip of its own)
+      if (RTX_NODE_KIND((uint32_t)unit) == PROG_NODE_END && (MEDIA != MEDIA_ALL || mode == 0) && (DEFER || ret_tail == 0)) running = false;
+    }
   }
   best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
   return deferred;
