@@ -408,7 +408,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
 #define RT_SHADE_KEYS 16u             // material class << 1 | sphere
 #ifndef RT_SHADE_LDS_TABLES
-#define RT_SHADE_LDS_TABLES 8192      // bytes of LDS for the small scene tables (0 = leave them in global memory)
+#define RT_SHADE_LDS_TABLES 16384     // bytes of LDS for the small scene tables (0 = leave them in global memory)
 #endif
 #ifndef RT_SHADE_DROP
 #define RT_SHADE_DROP 1
@@ -426,44 +426,47 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   __shared__ uint32_t s_kind[RT_SHADE_CHUNK];  // hit kind of the sorted entries: the shading pass starts its chain of dependent loads from LDS
   if (n != 0 && threadIdx.x == 0) atomicMin(&c->sh_start, (unsigned long long)wall_clock64());
 #if RT_SHADE_LDS_TABLES
-  // Small material, texture, light and transform tables are staged in LDS: shade_bounce reaches them through chains
-  // of dependent loads (hit -> material -> texture, light -> its primitive), and with two waves per SIMD every
-  // round trip to the L2 shows.  The table pointers of this kernel's copy of the scene then point into LDS.
+  // Small scene tables are staged in LDS: shade_bounce reaches them through chains of dependent loads (hit ->
+  // material -> texture, light -> its primitive, read twice per diffuse bounce by HittablePDF::generate and ::value),
+  // and with two waves per SIMD every round trip to the L2 shows.  Each table that still fits the budget is copied, in
+  // the order below; the table pointers of this kernel's copy of the scene then point into LDS.
   __shared__ __attribute__((aligned(16))) unsigned char s_tables[RT_SHADE_LDS_TABLES];
-  {
-    const uint32_t bm = S.n_materials * (uint32_t)sizeof(rtx_material), bt = S.n_textures * (uint32_t)sizeof(rtx_texture);
-    const uint32_t bl = S.n_lights * (uint32_t)sizeof(rtx_light), bx = S.n_xforms * (uint32_t)sizeof(rtx_xform), bo = S.n_xform_ops * (uint32_t)sizeof(rtx_xform_op);
-    if ((unsigned long long)bm + bt + bl + bx + bo <= RT_SHADE_LDS_TABLES && n != 0) {   // every size is a multiple of 8
-      const uint64_t* src[5] = {(const uint64_t*)S.materials, (const uint64_t*)S.textures, (const uint64_t*)S.lights, (const uint64_t*)S.xforms, (const uint64_t*)S.xform_ops};
-      const uint32_t bytes[5] = {bm, bt, bl, bx, bo};
-      uint32_t at = 0;
-      for (int t = 0; t < 5; ++t) {
-        uint64_t* dst = (uint64_t*)(s_tables + at);
-        for (uint32_t k = threadIdx.x; k < bytes[t] / 8u; k += 256u) dst[k] = src[t][k];
-        at += bytes[t];
+  if (n != 0) {
+    const rtx_light* g_lights = S.lights;   // the global copy: the light primitives are found through it
+    uint32_t at = 0;
+    auto stage = [&](const void* src, uint32_t bytes) -> const void* {   // bytes: a multiple of 8
+      if (bytes == 0 || at + bytes > RT_SHADE_LDS_TABLES) return nullptr;
+      uint64_t* dst = (uint64_t*)(s_tables + at);
+      for (uint32_t k = threadIdx.x; k < bytes / 8u; k += 256u) dst[k] = ((const uint64_t*)src)[k];
+      at += bytes;
+      return dst;
+    };
+    if (const void* p = stage(S.lights, S.n_lights * (uint32_t)sizeof(rtx_light))) S.lights = (const rtx_light*)p;
+    if (S.n_lights && at + S.n_lights * (uint32_t)(sizeof(rtx_quad) + sizeof(rtx_sphere)) <= RT_SHADE_LDS_TABLES) {
+      uint64_t* lq = (uint64_t*)(s_tables + at);
+      uint64_t* ls = lq + S.n_lights * (sizeof(rtx_quad) / 8u);
+      const uint32_t uq = (uint32_t)sizeof(rtx_quad) / 8u, us = (uint32_t)sizeof(rtx_sphere) / 8u;
+      for (uint32_t k = threadIdx.x; k < S.n_lights * uq; k += 256u) {
+        const rtx_light L = g_lights[k / uq];
+        lq[k] = L.kind == RTX_NODE_QUAD ? ((const uint64_t*)&S.quads[L.idx])[k % uq] : 0ull;
       }
-      S.materials = (const rtx_material*)s_tables;
-      S.textures = (const rtx_texture*)(s_tables + bm);
-      S.lights = (const rtx_light*)(s_tables + bm + bt);
-      S.xforms = (const rtx_xform*)(s_tables + bm + bt + bl);
-      S.xform_ops = (const rtx_xform_op*)(s_tables + bm + bt + bl + bx);
-      // the lights' own primitive records (read twice per diffuse bounce: HittablePDF::generate and ::value)
-      const uint32_t used = bm + bt + bl + bx + bo;
-      const uint32_t bq = S.n_lights * (uint32_t)sizeof(rtx_quad), bs = S.n_lights * (uint32_t)sizeof(rtx_sphere);
-      if ((unsigned long long)used + bq + bs <= RT_SHADE_LDS_TABLES) {
-        uint64_t* lq = (uint64_t*)(s_tables + used);
-        uint64_t* ls = (uint64_t*)(s_tables + used + bq);
-        const uint32_t uq = (uint32_t)sizeof(rtx_quad) / 8u, us = (uint32_t)sizeof(rtx_sphere) / 8u;
-        for (uint32_t i = 0; i < S.n_lights; ++i) {
-          const rtx_light L = ((const rtx_light*)src[2])[i];   // from global memory: the LDS copy is not complete yet
-          if (L.kind == RTX_NODE_QUAD) { const uint64_t* q = (const uint64_t*)&S.quads[L.idx]; for (uint32_t k = threadIdx.x; k < uq; k += 256u) lq[i * uq + k] = q[k]; }
-          else if (L.kind == RTX_NODE_SPHERE) { const uint64_t* q = (const uint64_t*)&S.spheres[L.idx]; for (uint32_t k = threadIdx.x; k < us; k += 256u) ls[i * us + k] = q[k]; }
-        }
-        S.light_quads = (const rtx_quad*)lq;
-        S.light_spheres = (const rtx_sphere*)ls;
+      for (uint32_t k = threadIdx.x; k < S.n_lights * us; k += 256u) {
+        const rtx_light L = g_lights[k / us];
+        ls[k] = L.kind == RTX_NODE_SPHERE ? ((const uint64_t*)&S.spheres[L.idx])[k % us] : 0ull;
       }
-      __syncthreads();
+      at += S.n_lights * (uint32_t)(sizeof(rtx_quad) + sizeof(rtx_sphere));
+      S.light_quads = (const rtx_quad*)lq;
+      S.light_spheres = (const rtx_sphere*)ls;
     }
+    if (const void* p = stage(S.xform_ops, S.n_xform_ops * (uint32_t)sizeof(rtx_xform_op))) {
+      S.xform_ops = (const rtx_xform_op*)p;
+      if (const void* x = stage(S.xforms, S.n_xforms * (uint32_t)sizeof(rtx_xform))) S.xforms = (const rtx_xform*)x;
+    } else if (S.n_xform_ops == 0) {
+      if (const void* x = stage(S.xforms, S.n_xforms * (uint32_t)sizeof(rtx_xform))) S.xforms = (const rtx_xform*)x;
+    }
+    if (const void* p = stage(S.materials, S.n_materials * (uint32_t)sizeof(rtx_material))) S.materials = (const rtx_material*)p;
+    if (const void* p = stage(S.textures, S.n_textures * (uint32_t)sizeof(rtx_texture))) S.textures = (const rtx_texture*)p;
+    __syncthreads();
   }
 #endif
   // the queue is handed out dynamically, one chunk at a time: the trip count is the same for every thread of a
