@@ -210,7 +210,8 @@ typedef struct rtx_scene rtx_scene;
 /* ------------------------------------------------------------ entry points */
 
 /* One context per process and GPU.  device_ids may be NULL (device 0).  n_devices must be 1: multi-GPU runs use
- * one process per GPU and sum accumulators outside. */
+ * one process per GPU, each rendering its own range of sample indices, and sum the accumulators outside (the
+ * library itself does no communication). */
 rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context** out);
 void rtx_context_destroy(rtx_context* ctx);
 /* Message of the last failing call on this context (or of the last failing context-less call when ctx is NULL). */

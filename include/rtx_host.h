@@ -7,8 +7,8 @@
  *
  * The reference's traits have no introspection hook (hittable.rs:97-115), so
  * a trait-object graph cannot be flattened from outside; a binding therefore
- * calls these constructors from the reference's own `new` functions (see
- * INTEGRATION.md).  Handles are small non-negative integers local to a
+ * calls these constructors from the reference's own `new` functions, one
+ * provided method per trait that re-records the object.  Handles are small non-negative integers local to a
  * session; a negative return value is an error (rtxh_last_error).
  *
  * Primitive ids and material ids (reported by the first-hit AOV) are creation
