@@ -158,8 +158,11 @@ def main():
         p_drop = st.get("roulette_drops", 0) / max(1.0, st["segments"])
         shade_bytes = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
         cands = [("k_render_fused", st["render_ms"], st["launches"], BOUNCE_BYTES, None)] if fused else [
+            # a new camera path (one segment in paths / segments) has no hit from the head-section launch to read: the
+            # world-program launch walks it from the start of the program
             ("k_wf_traverse<true,false,1>", st["traverse_ms"], st["traverse_launches"],
-             TRAVERSE_BYTES if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT, TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
+             TRAVERSE_BYTES - 16.0 * paths / max(1.0, segments) if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT,
+             TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
             ("k_wf_shade", st["shade_ms"], st["shade_launches"], shade_bytes, SHADE_PMC_TRAFFIC_PER_SEGMENT)]
         rl = []
         for name, ms, n_launch, seg_bytes, pmc in cands:

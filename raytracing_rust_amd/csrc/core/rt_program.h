@@ -97,7 +97,7 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
-    S.head_end = head_end; S._pad_scene = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
+    S.head_end = head_end; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
     return S;
   }
 

@@ -57,7 +57,9 @@ struct Scene : rtx_scene_desc {
                         // before it are all a walk with DEFER = true can reach
   uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
-  uint32_t _pad_scene;
+  uint32_t fresh_in_main;  // wavefront pipeline, with a head section: 1 = the head stream covers the survivors only and the
+                           // world-program launch walks new camera paths from the start of the program (their waves are
+                           // coherent: the per-ray walk serves them better than the stream)
   // optional copies of the lights' primitive records, indexed like `lights` (null: read quads[] / spheres[]); the
   // wavefront shading kernel points them at LDS
   const rtx_quad* light_quads;

@@ -221,7 +221,11 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   // hit the head section found; media boundary programs sit in front of the world program, so a scene with general
   // media still stages the image from its start.
   const bool behind_head = !TAIL && S.head_end != 0;
-  const uint32_t first_unit = TAIL ? S.tail_begin : ((behind_head && MM != MEDIA_ALL) ? ((S.head_end + 1u) & ~1u) : 0u);
+  // ... except for the new camera paths of the iteration when S.fresh_in_main is set: they sit behind the survivors
+  // (from gen_slot on), have not been through the head stream and are walked here from the start of the program
+  const bool fresh_whole = behind_head && S.fresh_in_main != 0;
+  const uint32_t fresh_from = fresh_whole ? c->gen_slot : 0xFFFFFFFFu;
+  const uint32_t first_unit = TAIL ? S.tail_begin : ((behind_head && !fresh_whole && MM != MEDIA_ALL) ? ((S.head_end + 1u) & ~1u) : 0u);
   const uint32_t end_unit = (!TAIL && S.tail_begin) ? S.tail_begin : S.n_units;
   const uint64_t* prog = S.prog;
 #if defined(RT_PROF)
@@ -276,10 +280,11 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       walk_program<MEDIA_NONE, false>(S, prog, S.tail_begin, active, rs, tm, 0.001, t_so_far, hit, false, rng, bounce, h.uv + 2 * (size_t)idx);
       if (active && hit_any(hit)) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
     } else {
-      const double t0 = behind_head ? h.t[idx] : RT_INF;
+      const bool behind = behind_head && idx < fresh_from;
+      const double t0 = behind ? h.t[idx] : RT_INF;
       RT_KPROF_ADD(14, kp_pass);
-      const uint32_t kind0 = behind_head ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind_head ? h.ctx[idx] : 0u;
-      const bool deferred = walk_program<MM, true>(S, prog, behind_head ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
+      const uint32_t kind0 = behind ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind ? h.ctx[idx] : 0u;
+      const bool deferred = walk_program<MM, true>(S, prog, behind ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
                                                    MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0);
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
       RT_KPROF_ADD(11, kp_pass);
@@ -368,7 +373,7 @@ template <bool USE_LDS, bool TAIL>
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t cap, WfCounters* c, WfQueue q, WfHits h,
                                                     const uint32_t* __restrict__ defer_list) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
-  const uint32_t n = TAIL ? c->n_defer : c->n_in;
+  const uint32_t n = TAIL ? c->n_defer : (S.fresh_in_main ? c->gen_slot : c->n_in);   // the head stream may leave the new paths out
   if (blockIdx.x * blockDim.x >= n) return;
   const uint32_t first_unit = TAIL ? S.tail_begin : 0u;
   const uint32_t end_unit = TAIL ? S.n_units : ((S.head_end + 2u) & ~1u);   // the SYNC that ends the head section included
@@ -1077,7 +1082,15 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   Scene dev = sc->dev;
   dev.head_end = head_end;
-  const uint32_t main_first = (head_end && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
+  // New camera paths are coherent (a wave holds one stratified sample of an 8 x 8 pixel tile): the per-ray walk with its
+  // votes serves them better than the stream (final scene, camera rays only: 54.9 ms per 448 M rays through head and
+  // world program in one walk against 25.5 + 42.3 ms streamed and then walked).  When the head section fits LDS next to
+  // the rest of the world program, the head stream therefore covers the survivors only.  RTX_WF_FRESH=0 turns it off.
+  const char* fresh_env = getenv("RTX_WF_FRESH");
+  const bool fresh_in_main = head_end != 0 && !(fresh_env && atoi(fresh_env) == 0) &&
+                             (size_t)(tail_begin ? tail_begin : n_units) * 8 + (tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0) <= kLdsBudget;
+  dev.fresh_in_main = fresh_in_main ? 1u : 0u;
+  const uint32_t main_first = (head_end && !fresh_in_main && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
   const size_t main_bytes = (size_t)((tail_begin ? tail_begin : n_units) - main_first) * 8;
   const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
   const bool main_lds = main_bytes + defer_bytes <= kLdsBudget;
@@ -1231,7 +1244,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev._pad_scene = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
+  sc->dev.head_end = prog.head_end; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
