@@ -59,7 +59,7 @@ struct Scene : rtx_scene_desc {
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
   uint32_t fresh_in_main;  // wavefront pipeline, with a head section: 1 = the head stream covers the survivors only and the
                            // world-program launch walks new camera paths from the start of the program (their waves are
-                           // coherent: the per-ray walk serves them better than the stream)
+                           // coherent: the per-ray walk serves them better than the stream); 2 = it also generates them
   // optional copies of the lights' primitive records, indexed like `lights` (null: read quads[] / spheres[]); the
   // wavefront shading kernel points them at LDS
   const rtx_quad* light_quads;
@@ -411,14 +411,16 @@ enum { MEDIA_NONE = 0, MEDIA_SPHERES = 1, MEDIA_ALL = 2 };
 template <int MEDIA, bool DEFER, class RaySrc>
 RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                         double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
-                        double* stale_uv, uint32_t kind0 = RTX_NODE_MAKE(RTX_NODE_NONE, 0), uint32_t ctx0 = 0) {
+                        double* stale_uv, uint32_t kind0 = RTX_NODE_MAKE(RTX_NODE_NONE, 0), uint32_t ctx0 = 0,
+                        bool have_start = false, V3 start_o = V3(), V3 start_d = V3()) {
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8, CL_MEDIUM_S = 9 };
   uint32_t cur = 0;
   uint32_t ret_tail = 0;  // DEFER = false: where to continue after the deferred program's END (0 = not inside it)
   bool deferred = false;
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
-  if (active) lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
+  // have_start: the caller already holds the world ray (start_o, start_d: the values `rs` will return later)
+  if (active) lr = have_start ? lray_from_ops(prog, 0, start_o, start_d) : lray_from_ops(prog, 0, rs.origin(), rs.dir());
   uint32_t i = begin;
   double tmin = tmin0, tmax = tmax0;
   uint32_t hit_kind = kind0, hit_ctx = ctx0;  // the hit an earlier part of the same walk found at tmax0, if any

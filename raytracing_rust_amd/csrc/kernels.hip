@@ -154,35 +154,45 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
 // Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, pixel), pixels enumerated tile by tile
 // (8 x 8, clipped at the rectangle's edges) so that the 64 lanes of a wave start the same stratified sample of
 // neighbouring pixels.  Path k of the iteration goes to slot gen_slot + k.
+// Path k of an iteration's new camera paths -> pixel (i, j) and sample index s.
+__device__ __forceinline__ void wf_path_coords(const rtx_camera_desc& cam, const WfFrame& fr, uint32_t s0, uint32_t r0, uint32_t k,
+                                               int& i, int& j, int& s) {
+  const uint32_t W = (uint32_t)fr.w, H = (uint32_t)fr.h;
+  const uint32_t r = r0 + k;                         // < per_sample + capacity, fits 32 bits (checked by the host)
+  const uint32_t so = r / fr.per_sample, rem = r - so * fr.per_sample;
+  const uint32_t row_px = W * 8u;
+  const uint32_t ty = rem / row_px, r2 = rem - ty * row_px;
+  const uint32_t hy = H - 8u * ty < 8u ? H - 8u * ty : 8u;
+  const uint32_t tile_px = 8u * hy;
+  uint32_t tx = r2 / tile_px;
+  if (tx > (W - 1u) / 8u) tx = (W - 1u) / 8u;
+  const uint32_t r3 = r2 - tx * tile_px;
+  const uint32_t wx = W - 8u * tx < 8u ? W - 8u * tx : 8u;
+  const uint32_t ly = r3 / wx, lx = r3 - ly * wx;
+  i = fr.x0 + (int)(8u * tx + lx); j = fr.y0 + (int)(8u * ty + ly);
+  s = fr.sample_begin + (int)(s0 + so);
+  (void)cam;
+}
+// The queue record of a new camera path (throughput 1, full depth, bounce 0).
+__device__ __forceinline__ void wf_store_new_path(const WfQueue& q, uint32_t cap, uint32_t slot, const Ray& ray, uint32_t pixel, int s, int max_depth) {
+  double* f = q.f + slot;
+  f[0 * (size_t)cap] = ray.o.x; f[1 * (size_t)cap] = ray.o.y; f[2 * (size_t)cap] = ray.o.z;
+  f[3 * (size_t)cap] = ray.d.x; f[4 * (size_t)cap] = ray.d.y; f[5 * (size_t)cap] = ray.d.z;
+  f[6 * (size_t)cap] = ray.tm;
+  f[7 * (size_t)cap] = 1.0; f[8 * (size_t)cap] = 1.0; f[9 * (size_t)cap] = 1.0;
+  uint32_t* u = q.u + slot;
+  u[0] = pixel; u[(size_t)cap] = (uint32_t)s; u[2 * (size_t)cap] = (uint32_t)max_depth << 16;
+}
 __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame fr, unsigned long long seed, uint32_t cap,
                                                    const WfCounters* c, WfQueue q) {
   const uint32_t count = c->gen_count, slot0 = c->gen_slot, s0 = c->gen_sample, r0 = c->gen_rem;
-  const uint32_t W = (uint32_t)fr.w, H = (uint32_t)fr.h;
   for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += gridDim.x * blockDim.x) {
-    const uint32_t r = r0 + idx;                       // < per_sample + capacity, fits 32 bits (checked by the host)
-    const uint32_t so = r / fr.per_sample, rem = r - so * fr.per_sample;
-    const uint32_t row_px = W * 8u;
-    const uint32_t ty = rem / row_px, r2 = rem - ty * row_px;
-    const uint32_t hy = H - 8u * ty < 8u ? H - 8u * ty : 8u;
-    const uint32_t tile_px = 8u * hy;
-    uint32_t tx = r2 / tile_px;
-    if (tx > (W - 1u) / 8u) tx = (W - 1u) / 8u;
-    const uint32_t r3 = r2 - tx * tile_px;
-    const uint32_t wx = W - 8u * tx < 8u ? W - 8u * tx : 8u;
-    const uint32_t ly = r3 / wx, lx = r3 - ly * wx;
-    const int i = fr.x0 + (int)(8u * tx + lx), j = fr.y0 + (int)(8u * ty + ly);
-    const int s = fr.sample_begin + (int)(s0 + so);
-    const uint32_t slot = slot0 + idx;
+    int i, j, s;
+    wf_path_coords(cam, fr, s0, r0, idx, i, j, s);
     const uint32_t pixel = (uint32_t)(j * cam.image_width + i);
     PathRng rng = rng_make(seed, pixel, (uint32_t)s);
     Ray ray = camera_ray(cam, i, j, s, rng);
-    double* f = q.f + slot;
-    f[0 * (size_t)cap] = ray.o.x; f[1 * (size_t)cap] = ray.o.y; f[2 * (size_t)cap] = ray.o.z;
-    f[3 * (size_t)cap] = ray.d.x; f[4 * (size_t)cap] = ray.d.y; f[5 * (size_t)cap] = ray.d.z;
-    f[6 * (size_t)cap] = ray.tm;
-    f[7 * (size_t)cap] = 1.0; f[8 * (size_t)cap] = 1.0; f[9 * (size_t)cap] = 1.0;
-    uint32_t* u = q.u + slot;
-    u[0] = pixel; u[(size_t)cap] = (uint32_t)s; u[2 * (size_t)cap] = (uint32_t)cam.max_depth << 16;
+    wf_store_new_path(q, cap, slot0 + idx, ray, pixel, s, cam.max_depth);
   }
 }
 
@@ -208,10 +218,10 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 //
 // MM (MEDIA_NONE / MEDIA_SPHERES / MEDIA_ALL) is what the world program needs for its media: a program without
 // general MEDIUM units runs the variant without the boundary-program machinery, which saves it registers.
-template <bool USE_LDS, bool TAIL, int MM>
+template <bool USE_LDS, bool TAIL, int MM, bool GEN = false>
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, WfCounters* c,
                                                       WfQueue q, WfHits h, uint32_t* __restrict__ defer_list,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats, rtx_camera_desc cam, WfFrame fr) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
   const uint32_t n = TAIL ? c->n_defer : c->n_in;
   if (blockIdx.x * blockDim.x >= n) return;
@@ -225,6 +235,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   // (from gen_slot on), have not been through the head stream and are walked here from the start of the program
   const bool fresh_whole = behind_head && S.fresh_in_main != 0;
   const uint32_t fresh_from = fresh_whole ? c->gen_slot : 0xFFFFFFFFu;
+  // S.fresh_in_main == 2: no ray generation launch has run; this kernel makes the camera rays of the new paths itself
+  // (Camera::get_ray), stores their queue records for the kernels that follow and walks them from registers
+  const bool fresh_gen = GEN && fresh_whole && S.fresh_in_main == 2u;   // GEN: the variant compiled with that code
+  const uint32_t gen_s0 = fresh_gen ? c->gen_sample : 0u, gen_r0 = fresh_gen ? c->gen_rem : 0u;
   const uint32_t first_unit = TAIL ? S.tail_begin : ((behind_head && !fresh_whole && MM != MEDIA_ALL) ? ((S.head_end + 1u) & ~1u) : 0u);
   const uint32_t end_unit = (!TAIL && S.tail_begin) ? S.tail_begin : S.n_units;
   const uint64_t* prog = S.prog;
@@ -265,10 +279,23 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
     const uint32_t idx = TAIL ? defer_list[active ? k : 0] : (active ? k : 0);
     RayMem rs;
     rs.f = q.f + idx; rs.cap = cap;
-    const double tm = rs.f[6 * (size_t)cap];
+    const bool gen = GEN && !TAIL && fresh_gen && active && idx >= fresh_from;
+    Ray nray;
+    nray.o = v3(0, 0, 0); nray.d = v3(0, 0, 1); nray.tm = 0.0;
     PathRng rng = rng_make(seed, 0, 0);
     uint32_t bounce = 0;
-    if (!TAIL && MM != MEDIA_NONE) {
+    if (gen) {
+      int pi, pj, ps;
+      wf_path_coords(cam, fr, gen_s0, gen_r0, idx - fresh_from, pi, pj, ps);
+      const uint32_t pixel = (uint32_t)(pj * cam.image_width + pi);
+      rng = rng_make(seed, pixel, (uint32_t)ps);
+      PathRng crng = rng;
+      nray = camera_ray(cam, pi, pj, ps, crng);
+      wf_store_new_path(q, cap, idx, nray, pixel, ps, cam.max_depth);
+    }
+    double tm = nray.tm;
+    if (!gen) tm = rs.f[6 * (size_t)cap];
+    if (!TAIL && MM != MEDIA_NONE && !gen) {
       const uint32_t* u = q.u + idx;
       rng = rng_make(seed, u[0], u[(size_t)cap]);
       bounce = u[2 * (size_t)cap] & 0xFFFFu;
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       RT_KPROF_ADD(14, kp_pass);
       const uint32_t kind0 = behind ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind ? h.ctx[idx] : 0u;
       const bool deferred = walk_program<MM, true>(S, prog, behind ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
-                                                   MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0);
+                                                   MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0, gen, nray.o, nray.d);
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
       RT_KPROF_ADD(11, kp_pass);
       if (collect) {
@@ -993,6 +1020,9 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
@@ -1089,14 +1119,18 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const char* fresh_env = getenv("RTX_WF_FRESH");
   const bool fresh_in_main = head_end != 0 && !(fresh_env && atoi(fresh_env) == 0) &&
                              (size_t)(tail_begin ? tail_begin : n_units) * 8 + (tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0) <= kLdsBudget;
-  dev.fresh_in_main = fresh_in_main ? 1u : 0u;
+  // ... and makes their camera rays itself instead of reading them back from a ray generation launch (one pipeline:
+  // 2057 against 1947 Msamples/s; RTX_WF_FRESH=1 keeps the separate launch)
+  dev.fresh_in_main = fresh_in_main ? ((fresh_env && atoi(fresh_env) == 1) ? 1u : 2u) : 0u;
   const uint32_t main_first = (head_end && !fresh_in_main && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
   const size_t main_bytes = (size_t)((tail_begin ? tail_begin : n_units) - main_first) * 8;
   const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
   const bool main_lds = main_bytes + defer_bytes <= kLdsBudget;
   // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
   const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
-  auto k_main = main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
+  const bool gen_in_main = dev.fresh_in_main == 2u;   // then main_lds holds (the whole world program fits LDS)
+  auto k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
+              : main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
                          : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
   const unsigned blocks256 = cap / 256;
   const unsigned trav_blocks = (unsigned)ctx->n_cus;
@@ -1129,7 +1163,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       for (int it = 0; it < chunk; ++it) {
         WfQueue qin = L.q[r.cur], qout = L.q[r.cur ^ 1];
         hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, L.c, cap, r.fr.per_sample, ctx->d_counters);
-        hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, s, *cam, r.fr, seed, cap, L.c, qin);
+        if (dev.fresh_in_main != 2u) hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, s, *cam, r.fr, seed, cap, L.c, qin);
         if (head_end) {  // the head section of the world program, streamed
           TimedSpan sh;
           const bool timed_head = span_begin(ctx, s, sh, 3);
@@ -1139,7 +1173,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
             hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
           if (timed_head) span_end(ctx, s, sh);
         }
-        hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+        hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
         if (tail_begin) {  // the deferred section for the rays that passed its root box
           TimedSpan st;
           const bool timed_tail = span_begin(ctx, s, st, 2);
@@ -1148,9 +1182,9 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
           else if (stream_tail)
             hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (tail_lds)
-            hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+            hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
           else
-            hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters);
+            hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
           if (timed_tail) span_end(ctx, s, st);
         }
         hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, L.c, qin, L.hits, qout, accum_dev, ctx->d_counters, sc->mat_class);
