@@ -234,10 +234,10 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
   // ... except for the new camera paths of the iteration when S.fresh_in_main is set: they sit behind the survivors
   // (from gen_slot on), have not been through the head stream and are walked here from the start of the program
   const bool fresh_whole = behind_head && S.fresh_in_main != 0;
-  const uint32_t fresh_from = fresh_whole ? c->gen_slot : 0xFFFFFFFFu;
   // S.fresh_in_main == 2: no ray generation launch has run; this kernel makes the camera rays of the new paths itself
   // (Camera::get_ray), stores their queue records for the kernels that follow and walks them from registers
-  const bool fresh_gen = GEN && fresh_whole && S.fresh_in_main == 2u;   // GEN: the variant compiled with that code
+  const bool fresh_gen = GEN && !TAIL && S.fresh_in_main == 2u;   // GEN: the variant compiled with that code
+  const uint32_t fresh_from = (fresh_whole || fresh_gen) ? c->gen_slot : 0xFFFFFFFFu;
   const uint32_t gen_s0 = fresh_gen ? c->gen_sample : 0u, gen_r0 = fresh_gen ? c->gen_rem : 0u;
   const uint32_t first_unit = TAIL ? S.tail_begin : ((behind_head && !fresh_whole && MM != MEDIA_ALL) ? ((S.head_end + 1u) & ~1u) : 0u);
   const uint32_t end_unit = (!TAIL && S.tail_begin) ? S.tail_begin : S.n_units;
@@ -1128,6 +1128,8 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const bool main_lds = main_bytes + defer_bytes <= kLdsBudget;
   // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
   const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
+  // without a head section every path starts at the start of the program anyway: the kernel only has to make the rays
+  if (head_end == 0 && main_lds && !(fresh_env && (atoi(fresh_env) == 0 || atoi(fresh_env) == 1))) dev.fresh_in_main = 2u;
   const bool gen_in_main = dev.fresh_in_main == 2u;   // then main_lds holds (the whole world program fits LDS)
   auto k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
               : main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
