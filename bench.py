@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
-# Algorithmic bytes per ray segment.  World-program traversal kernel (k_wf_traverse<true,false,1>, the kernel with the
+# Algorithmic bytes per ray segment.  World-program traversal kernel (k_wf_traverse<true,false,1,true>, the kernel with the
 # largest share of GPU time): reads the ray (origin, direction, time: 7 doubles), the path's RNG address because the
 # scene has media (pixel, sample, bounce: 3 u32) and the hit the head-section launch left (t f64, kind_idx u32, ctx
 # u32); writes the hit: 56 + 12 + 16 + 16 = 100 B (84 B when the head section is not walked separately).  A whole
@@ -32,10 +32,10 @@ TRAVERSE_BYTES = 100
 TRAVERSE_BYTES_UNSPLIT = 84
 BOUNCE_BYTES = 390
 # HBM-side traffic of that kernel per segment, from rocprofv3 PMC passes over this command with --rows 10 --steps 1
-# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 48.97e9 B doubled (the gfx950 half-count
+# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 42.92e9 B doubled (the gfx950 half-count
 # correction; it is calibrated for 16-byte loads and these are 8- and 4-byte ones, so an upper bound; the algorithmic
-# reads are 82.7e9 B) + WRITE_SIZE 18.07e9 B (hit records: 17.1e9 B).
-TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 48.97e9 + 18.07e9) / 1.0699e9
+# reads are 52.3e9 B) + WRITE_SIZE 59.11e9 B (hit records 17.1e9 B, queue records of the new paths 41.2e9 B).
+TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 42.92e9 + 59.11e9) / 1.0699e9
 # The same for the shading kernel: FETCH_SIZE 136.3e9 B doubled + WRITE_SIZE 68.80e9 B (algorithmic: about 113e9 read,
 # 57.2e9 of survivor records and dead entries + up to 10.8e9 of pixel atomics written).  The reads exceed the algorithmic bytes because
 # the kernel shades each chunk of 4096 queue entries in sorted order: a 128-byte line of a queue array holds 16
@@ -158,10 +158,10 @@ def main():
         p_drop = st.get("roulette_drops", 0) / max(1.0, st["segments"])
         shade_bytes = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
         cands = [("k_render_fused", st["render_ms"], st["launches"], BOUNCE_BYTES, None)] if fused else [
-            # a new camera path (one segment in paths / segments) has no hit from the head-section launch to read: the
-            # world-program launch walks it from the start of the program
-            ("k_wf_traverse<true,false,1>", st["traverse_ms"], st["traverse_launches"],
-             TRAVERSE_BYTES - 16.0 * paths / max(1.0, segments) if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT,
+            # a new camera path (one segment in paths / segments) is not read at all: the world-program launch makes its
+            # camera ray, writes its queue record (92 B) and its hit (16 B) and walks it from the start of the program
+            ("k_wf_traverse<true,false,1,true>", st["traverse_ms"], st["traverse_launches"],
+             TRAVERSE_BYTES + (108.0 - TRAVERSE_BYTES) * paths / max(1.0, segments) if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT,
              TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
             ("k_wf_shade", st["shade_ms"], st["shade_launches"], shade_bytes, SHADE_PMC_TRAFFIC_PER_SEGMENT)]
         rl = []
