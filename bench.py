@@ -195,7 +195,7 @@ def main():
                                    "paths per GPU per step",
                        "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator",
                        "pipelines_per_gpu": int(os.environ.get("RTX_WF_LANES", "4")),
-                       "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 26)))},
+                       "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 27)))},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
             "roofline": roofline,
         }

@@ -1064,8 +1064,8 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
 // depends on the one before it, so a single pipeline leaves CUs idle while every launch drains; independent pipelines
 // fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s): 1 pipeline 1928, 2: 1906,
 // 3 x 32 M paths in flight 1960, 4 x 16 M 1731, 4 x 32 M 1933, 4 x 64 M 2058, 5: 1691, 6: 1675.  Default: one pipeline per
-// 4 M camera paths of the call, at most four, each holding at most 64 M paths (14.7 GB) and no more than its share
-// of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
+// 4 M camera paths of the call, at most four, each holding at most 128 M paths (29.4 GB; 4 x 64 M 2189, 4 x 128 M 2231,
+// 3 x 96 M 2212) and no more than its share of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
   static unsigned v = 0;
   if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
@@ -1080,8 +1080,8 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const char* lanes_env = getenv("RTX_WF_LANES");
   const int want_lanes = lanes_env ? atoi(lanes_env) : (int)std::min<unsigned long long>(4ull, call_paths >> 22);
   const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
-  uint32_t cap = 1u << 26;
-  if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 26)) cap = (uint32_t)v; }
+  uint32_t cap = 1u << 27;
+  if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 27)) cap = (uint32_t)v; }
   {  // no more than a pipeline's share of the call needs (whole sample indices; at least 64 K)
     const unsigned long long share = per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes);
     if (share < cap) cap = (uint32_t)std::max<unsigned long long>(share, 65536ull);
