@@ -43,6 +43,7 @@ struct CompiledProgram {
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
+  uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes over static-sphere runs of this depth
   uint32_t defer_pos = 0;          // unit index of the DEFER unit
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
@@ -84,6 +85,7 @@ struct CompiledProgram {
     } else {
       world_begin = emit_range(d, d.world_begin, d.world_end, true);
     }
+    tail_near_depth = tail_begin ? near_depth_of_tail() : 0u;
     if (split_head) find_head(d);
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
@@ -97,11 +99,40 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
-    S.head_end = head_end; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
+    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
     return S;
   }
 
  private:
+  // Depth of the deferred section if it has the shape walk_stream_near needs: behind leading ENTER/NOP units, every
+  // box is followed either by exactly two box subtrees that fill it, or by static-sphere runs only.  0 = another shape.
+  uint32_t near_depth_of_tail() const {
+    uint32_t pos = tail_begin;
+    const uint32_t n = (uint32_t)units.size();
+    while (pos < n) {
+      const uint32_t k = RTX_NODE_KIND((uint32_t)units[pos]);
+      if (k == RTX_NODE_ENTER || k == PROG_NODE_NOP) pos += prog_record_units(units[pos]); else break;
+    }
+    uint32_t end = pos;
+    while (end < n && RTX_NODE_KIND((uint32_t)units[end]) != PROG_NODE_END) end += prog_record_units(units[end]);
+    if (end >= n) return 0;
+    const int dpt = near_depth(pos, end, 0);
+    return dpt > 0 ? (uint32_t)dpt : 0u;
+  }
+  int near_depth(uint32_t pos, uint32_t end, int level) const {   // -1: not the shape
+    if (level > 48 || pos >= end) return -1;
+    if (RTX_NODE_KIND((uint32_t)units[pos]) == RTX_NODE_BOX) {
+      const uint32_t c0 = pos, c1 = (uint32_t)(units[c0] >> 32);
+      if (c1 <= c0 || c1 >= end || RTX_NODE_KIND((uint32_t)units[c1]) != RTX_NODE_BOX || (uint32_t)(units[c1] >> 32) != end) return -1;
+      const int a = near_depth(c0 + PROG_BOX_UNITS, c1, level + 1), b = near_depth(c1 + PROG_BOX_UNITS, end, level + 1);
+      return (a < 0 || b < 0) ? -1 : 1 + std::max(a, b);
+    }
+    for (uint32_t p = pos; p < end; p += prog_record_units(units[p])) {
+      const uint32_t k = RTX_NODE_KIND((uint32_t)units[p]);
+      if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP) return -1;
+    }
+    return 0;
+  }
   static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }
   static uint64_t bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
 

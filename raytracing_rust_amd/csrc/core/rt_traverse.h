@@ -55,6 +55,8 @@ struct Scene : rtx_scene_desc {
   uint32_t n_units;
   uint32_t tail_begin;  // first unit of the deferred section's program (0 = the world program has none); the units
                         // before it are all a walk with DEFER = true can reach
+  uint32_t tail_near_depth;  // > 0: the deferred section is a binary tree of boxes over static-sphere runs of this depth;
+                             // walk_stream_near may walk it nearer child first
   uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
   uint32_t fresh_in_main;  // wavefront pipeline, with a head section: 1 = the head stream covers the survivors only and the
@@ -784,6 +786,157 @@ RT_UNROLL
       }
     }
     if (next != i) { RT_TRACE_STEP(cls == CL_CHEAP ? kind : 32u + (uint32_t)cls); i = next; unit = prog[i]; }
+  }
+}
+
+// Aabb::hit (slab_hit above, same arithmetic and decision) that also returns where the clipped interval begins.
+RT_HD bool slab_hit_entry(const double* b, const LRay& r, double tmin, double tmax, double& entry) {
+  const uint32_t nx = r.inv.x >= 0.0 ? 0u : 3u, ny = r.inv.y >= 0.0 ? 0u : 3u, nz = r.inv.z >= 0.0 ? 0u : 3u;
+  const double bnx = b[nx], bfx = b[3u - nx], bny = b[1u + ny], bfy = b[4u - ny], bnz = b[2u + nz], bfz = b[5u - nz];
+  double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
+  double nry = (bny - r.o.y) * r.inv.y, fry = (bfy - r.o.y) * r.inv.y;
+  double nrz = (bnz - r.o.z) * r.inv.z, frz = (bfz - r.o.z) * r.inv.z;
+  if (r.skip & 7u) {
+    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
+    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
+    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
+  }
+  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
+  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
+  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
+  entry = tmin;
+  return !(tmax <= tmin);
+}
+// Sphere::hit for a static sphere with an inclusive upper bound: a root equal to tmax is reported, so that the caller
+// can resolve the tie by program order (sphere_s_hit_t is this with the tie always lost, sphere.rs:99-101).
+RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, double tmin, double tmax, double& t) {
+  V3 oc = o - v3(s.cx, s.cy, s.cz);
+  double a = norm2(d);
+  double half_b = dot(oc, d);
+  double c = norm2(oc) - s.r * s.r;
+  double disc = half_b * half_b - a * c;
+  if (disc < 0.0) return false;
+  double sqrtd = sqrt(disc);
+  double root = (-half_b - sqrtd) / a;
+  if (!(tmin < root && root <= tmax)) {
+    root = (-half_b + sqrtd) / a;
+    if (!(tmin < root && root <= tmax)) return false;
+  }
+  t = root;
+  return true;
+}
+
+// walk_stream for a section that is a binary tree of boxes over runs of static spheres (the sphere cluster of the final
+// scene; the scene says whether its deferred section has that shape), with the NEARER child of every box walked first.
+// The reference walks left before right whatever the ray's direction (bvh.rs:94-102), so its tmax shrinks late; the
+// closest hit does not depend on the visiting order once ties are resolved the way the fixed order resolves them
+// (among hits with equal t the one that comes first in the program wins: a later sphere needs t < tmax, sphere.rs:99-101).
+// What a different order can change is which boxes the shrinking tmax culls, and that matters only for a hit that lies
+// on the very boundary of its own box (a ray through one of the six extreme points of a sphere, to the last bit) and
+// ties with another hit at once: such a ray may find the other sphere.  The deterministic first-hit query keeps the
+// reference's order; this walk serves rendering, where paths are random and images agree in distribution.
+//   stk: per-lane stack of unit positions (lane-private, stk[level * stk_stride]); depth = the tree's depth.
+// Per lane: i = a box not tested yet (`single`: only it; otherwise it and its sibling, the two children of a box that
+// passed), or a sphere run of the leaf whose units end at `end`.
+template <class Feed>
+RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride) {
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_BOX = 8, CL_DONE = 10 };
+  const double tmin = 0.001;
+  bool have = false, single = false;
+  uint32_t id = 0, i = begin, end = 0xFFFFFFFFu, sp = 0, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
+  uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  double tmax = RT_INF;
+  auto rs = feed.ray(0);
+  LRay lr;
+  lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  for (;;) {
+    if (have) {  // a lane whose units ran out takes the far child it left behind, or hands in its result
+      const uint32_t k = RTX_NODE_KIND((uint32_t)unit);
+      if (i >= end || k == PROG_NODE_END || k == PROG_NODE_SYNC) {
+        if (sp == 0) { feed.commit(id, tmax, hit_kind, hit_ctx); have = false; }
+        else { sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu; }
+      }
+    }
+    if (feed.more() && RT_WAVE_COUNT(!have) >= RT_STREAM_REFILL) {
+      uint32_t nid = 0;
+      if (feed.take(!have, nid)) {
+        id = nid; rs = feed.ray(id);
+        feed.start(id, tmax, hit_kind, hit_ctx);
+        lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
+        cur = 0; i = begin; unit = prog[i]; have = true; single = false; end = 0xFFFFFFFFu; sp = 0; best_pos = 0;
+      }
+    }
+    if (!RT_WAVE_ANY(have)) {
+      if (feed.more()) continue;
+      break;
+    }
+    const uint32_t kind_idx = (uint32_t)unit;
+    const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
+    int cls = CL_CHEAP;
+    if (!have || i >= end || kind == PROG_NODE_END || kind == PROG_NODE_SYNC) cls = CL_DONE;
+    else if (kind == RTX_NODE_BOX) cls = CL_BOX;
+    else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    if (RT_WAVE_ANY(cls == CL_CHEAP)) {
+      if (cls == CL_CHEAP) {
+        uint32_t next;
+        if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+          const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();
+          cur = idx;
+          lr = lray_from_ops(prog + i + 1, count, wo, wd);
+          next = i + 1 + PROG_XFORM_OP_UNITS * count;
+        } else {
+          next = i + prog_record_units(unit);
+        }
+        i = next; unit = prog[i];
+      }
+      continue;
+    }
+    const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_s = RT_WAVE_COUNT(cls == CL_SPHERE_S);
+    if (n_x > 0 && (n_s == 0 || n_x * RT_STREAM_LEAF_BIAS >= n_s)) {
+      // box steps in a tight loop, while the lanes on boxes outweigh the lanes waiting on a leaf
+      bool on_box = cls == CL_BOX;
+      int nb, ns, nd;
+      do {
+        if (on_box) {
+          // the box at i, and unless `single` its sibling (the two children of the box this lane came through)
+          const uint32_t c0 = i, c1 = (uint32_t)(unit >> 32);
+          const uint64_t u1 = single ? unit : prog[c1];
+          double e0 = 0.0, e1 = 0.0;
+          const bool p0 = slab_hit_entry((const double*)(prog + c0 + 1), lr, tmin, tmax, e0);
+          const bool p1 = !single && slab_hit_entry((const double*)(prog + c1 + 1), lr, tmin, tmax, e1);
+          RT_TRACE_STEP(RTX_NODE_BOX);
+          if (p0 || p1) {
+            const bool first0 = p0 && (!p1 || e0 <= e1);            // equal entries: the reference's order
+            if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
+            const uint32_t c = first0 ? c0 : c1;
+            end = (uint32_t)((first0 ? unit : u1) >> 32);
+            i = c + PROG_BOX_UNITS; unit = prog[i]; single = false;
+          } else if (sp > 0) {                                       // nothing here: on to the far child left behind
+            sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu;
+          } else {
+            i = 0xFFFFFFFFu - 1u; end = 0u;                          // the section is done: the top of the loop hands in
+          }
+        }
+        const uint32_t k2 = RTX_NODE_KIND((uint32_t)unit);
+        const bool fin = !have || i >= end || k2 == PROG_NODE_END || k2 == PROG_NODE_SYNC;
+        on_box = !fin && k2 == RTX_NODE_BOX;
+        nb = RT_WAVE_COUNT(on_box); nd = RT_WAVE_COUNT(fin);
+        ns = RT_WAVE_LANES - nb - nd;
+      } while (nb > 0 && (ns == 0 || nb * RT_STREAM_LEAF_BIAS >= ns) && !(nd >= RT_STREAM_REFILL));
+      continue;
+    }
+    if (cls == CL_SPHERE_S) {
+      for (uint32_t k = 0; k < count; ++k) {
+        double t;
+        const DSphere sph = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
+        const uint32_t pos = (i << 6) + k + 1u;                      // program order of this sphere (0 = before the section)
+        if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && (t < tmax || pos < best_pos)) {
+          tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; best_pos = pos;
+        }
+      }
+      RT_TRACE_STEP(32u + (uint32_t)CL_SPHERE_S);
+      i = i + 1 + PROG_SPHERE_S_UNITS * count; unit = prog[i < end ? i : begin];
+    }
   }
 }
 

@@ -396,7 +396,7 @@ struct QueueFeed {
   __device__ void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { ht[id] = tmax; hk[id] = kind; hc[id] = ctx; }
 };
 
-template <bool USE_LDS, bool TAIL>
+template <bool USE_LDS, bool TAIL, bool NEAR = false>
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t cap, WfCounters* c, WfQueue q, WfHits h,
                                                     const uint32_t* __restrict__ defer_list) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
@@ -417,7 +417,12 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.ht = h.t; feed.hk = h.kind_idx; feed.hc = h.ctx;
   feed.work = TAIL ? &c->work_tail : &c->work_head; feed.n = n; feed.n_waves = gridDim.x * (blockDim.x / 64u); feed.lane = threadIdx.x & 63u;
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
-  walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
+  if (NEAR) {  // the deferred section, nearer child first; the lanes' stacks sit behind the staged program
+    uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
+    walk_stream_near(S, prog, S.tail_begin, feed, stk, blockDim.x);
+  } else {
+    walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
+  }
 }
 
 // Shading kernel: everything ray_color does after world.hit (camera.rs:180-246) for every queued path.  A path that
@@ -1025,6 +1030,8 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
     ctx->wf_ready = true;
   }
@@ -1109,6 +1116,13 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const bool tail_lds = tail_bytes <= kLdsBudget;
   const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
   const bool stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
+  // The deferred section nearer child first (walk_stream_near), when it has the shape for it: RTX_WF_NEAR=0 keeps the
+  // reference's left-to-right order.  Each lane's stack (one unit position per tree level) lives in LDS.
+  const char* near_env = getenv("RTX_WF_NEAR");
+  const bool near_ok = stream_tail && sc->dev.tail_near_depth > 0 && !(near_env && atoi(near_env) == 0);
+  const size_t near_stack_bytes = (size_t)sc->dev.tail_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
+  const bool near_lds = near_ok && tail_lds && tail_bytes + near_stack_bytes <= kLdsBudget;
+  const bool near_global = near_ok && !tail_lds && near_stack_bytes <= kLdsBudget;
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   Scene dev = sc->dev;
   dev.head_end = head_end;
@@ -1179,7 +1193,11 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
         if (tail_begin) {  // the deferred section for the rays that passed its root box
           TimedSpan st;
           const bool timed_tail = span_begin(ctx, s, st, 2);
-          if (stream_tail && tail_lds)
+          if (stream_tail && near_lds)
+            hipLaunchKernelGGL((k_wf_stream<true, true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (stream_tail && near_global)
+            hipLaunchKernelGGL((k_wf_stream<false, true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (stream_tail && tail_lds)
             hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (stream_tail)
             hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
@@ -1280,7 +1298,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);

@@ -164,6 +164,27 @@ def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
     scene.close()
 
 
+@pytest.mark.parametrize("near", ["0", "1"])
+def test_deferred_section_nearer_child_first_traces_the_same_paths(gpu_ctx, monkeypatch, near):
+    """The deferred sphere cluster of the final scene is a binary tree of boxes over sphere runs; by default the stream
+    walks the nearer child of every box first (RTX_WF_NEAR=0: the reference's left-to-right order).  The closest hit
+    does not depend on the visiting order (ties go to the earlier sphere of the program either way), so both must
+    trace the fused pipeline's paths, which walks in the reference's order."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("final", gp, width=240, spp=16, depth=30)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=90, pipeline=_capi.PIPELINE_FUSED))
+    sa = gpu_ctx.stats()
+    monkeypatch.setenv("RTX_WF_NEAR", near)
+    gpu_ctx.reset_stats()
+    b = scene.render(cam, rt.render_opts(cam, seed=90, pipeline=_capi.PIPELINE_WAVEFRONT))
+    sb = gpu_ctx.stats()
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"] and sb["tail_launches"] > 0
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 @pytest.mark.parametrize("recipe", [recipes.large_bvh_beyond_lds, recipes.empty_lists_and_media, recipes.nested_transforms],
                          ids=lambda r: r.__name__)
 def test_pipelines_agree_on_recipes(gpu_ctx, recipe):
