@@ -838,6 +838,12 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 //   stk: per-lane stack of unit positions (lane-private, stk[level * stk_stride]); depth = the tree's depth.
 // Per lane: i = a box not tested yet (`single`: only it; otherwise it and its sibling, the two children of a box that
 // passed), or a sphere run of the leaf whose units end at `end`.
+#ifndef RT_NEAR_LEAF_BIAS
+#define RT_NEAR_LEAF_BIAS RT_STREAM_LEAF_BIAS
+#endif
+#ifndef RT_NEAR_REFILL
+#define RT_NEAR_REFILL RT_STREAM_REFILL
+#endif
 template <class Feed>
 RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride) {
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_BOX = 8, CL_DONE = 10 };
@@ -857,7 +863,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         else { sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu; }
       }
     }
-    if (feed.more() && RT_WAVE_COUNT(!have) >= RT_STREAM_REFILL) {
+    if (feed.more() && RT_WAVE_COUNT(!have) >= RT_NEAR_REFILL) {
       uint32_t nid = 0;
       if (feed.take(!have, nid)) {
         id = nid; rs = feed.ray(id);
@@ -892,7 +898,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
       continue;
     }
     const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_s = RT_WAVE_COUNT(cls == CL_SPHERE_S);
-    if (n_x > 0 && (n_s == 0 || n_x * RT_STREAM_LEAF_BIAS >= n_s)) {
+    if (n_x > 0 && (n_s == 0 || n_x * RT_NEAR_LEAF_BIAS >= n_s)) {
       // box steps in a tight loop, while the lanes on boxes outweigh the lanes waiting on a leaf
       bool on_box = cls == CL_BOX;
       int nb, ns, nd;
@@ -922,7 +928,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         on_box = !fin && k2 == RTX_NODE_BOX;
         nb = RT_WAVE_COUNT(on_box); nd = RT_WAVE_COUNT(fin);
         ns = RT_WAVE_LANES - nb - nd;
-      } while (nb > 0 && (ns == 0 || nb * RT_STREAM_LEAF_BIAS >= ns) && !(nd >= RT_STREAM_REFILL));
+      } while (nb > 0 && (ns == 0 || nb * RT_NEAR_LEAF_BIAS >= ns) && !(nd >= RT_NEAR_REFILL));
       continue;
     }
     if (cls == CL_SPHERE_S) {
