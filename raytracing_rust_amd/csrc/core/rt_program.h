@@ -43,7 +43,8 @@ struct CompiledProgram {
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
-  uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes over static-sphere runs of this depth
+  uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes of this depth (walk_stream_near's shape)
+  uint32_t head_near_depth = 0;    // > 0: so is the head section under its root box
   uint32_t defer_pos = 0;          // unit index of the DEFER unit
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
@@ -87,6 +88,11 @@ struct CompiledProgram {
     }
     tail_near_depth = tail_begin ? near_depth_of_tail() : 0u;
     if (split_head) find_head(d);
+    head_near_depth = 0;
+    if (head_end) {
+      const int dpt = near_depth(world_begin + PROG_BOX_UNITS, head_end, 0, true);
+      head_near_depth = dpt > 0 ? (uint32_t)dpt : 0u;
+    }
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
   }
@@ -99,13 +105,14 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
-    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
+    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
     return S;
   }
 
  private:
   // Depth of the deferred section if it has the shape walk_stream_near needs: behind leading ENTER/NOP units, every
-  // box is followed either by exactly two box subtrees that fill it, or by static-sphere runs only.  0 = another shape.
+  // box is followed either by exactly two box subtrees that fill it, or by leaf records only: static-sphere runs, and
+  // with `quads` (the head section) axis-aligned quads and BOX6 records behind their guards.  0 = another shape.
   uint32_t near_depth_of_tail() const {
     uint32_t pos = tail_begin;
     const uint32_t n = (uint32_t)units.size();
@@ -116,20 +123,27 @@ struct CompiledProgram {
     uint32_t end = pos;
     while (end < n && RTX_NODE_KIND((uint32_t)units[end]) != PROG_NODE_END) end += prog_record_units(units[end]);
     if (end >= n) return 0;
-    const int dpt = near_depth(pos, end, 0);
+    const int dpt = near_depth(pos, end, 0, false);
     return dpt > 0 ? (uint32_t)dpt : 0u;
   }
-  int near_depth(uint32_t pos, uint32_t end, int level) const {   // -1: not the shape
+  int near_depth(uint32_t pos, uint32_t end, int level, bool quads) const {   // -1: not the shape
     if (level > 48 || pos >= end) return -1;
-    if (RTX_NODE_KIND((uint32_t)units[pos]) == RTX_NODE_BOX) {
+    if (RTX_NODE_KIND((uint32_t)units[pos]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)units[pos]) != PROG_GUARD_IDX) {
       const uint32_t c0 = pos, c1 = (uint32_t)(units[c0] >> 32);
-      if (c1 <= c0 || c1 >= end || RTX_NODE_KIND((uint32_t)units[c1]) != RTX_NODE_BOX || (uint32_t)(units[c1] >> 32) != end) return -1;
-      const int a = near_depth(c0 + PROG_BOX_UNITS, c1, level + 1), b = near_depth(c1 + PROG_BOX_UNITS, end, level + 1);
+      if (c1 <= c0 || c1 >= end || RTX_NODE_KIND((uint32_t)units[c1]) != RTX_NODE_BOX || RTX_NODE_IDX((uint32_t)units[c1]) == PROG_GUARD_IDX ||
+          (uint32_t)(units[c1] >> 32) != end) return -1;
+      const int a = near_depth(c0 + PROG_BOX_UNITS, c1, level + 1, quads), b = near_depth(c1 + PROG_BOX_UNITS, end, level + 1, quads);
       return (a < 0 || b < 0) ? -1 : 1 + std::max(a, b);
     }
     for (uint32_t p = pos; p < end; p += prog_record_units(units[p])) {
       const uint32_t k = RTX_NODE_KIND((uint32_t)units[p]);
-      if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP) return -1;
+      if (k == RTX_NODE_BOX && quads) {   // only a guard, with its BOX6 record right behind it
+        const uint32_t rec = p + PROG_BOX_UNITS;
+        if (RTX_NODE_IDX((uint32_t)units[p]) != PROG_GUARD_IDX || rec >= end || RTX_NODE_KIND((uint32_t)units[rec]) != PROG_NODE_BOX6 ||
+            (uint32_t)(units[p] >> 32) != rec + PROG_BOX6_UNITS) return -1;
+        continue;
+      }
+      if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP && !(quads && (k == PROG_NODE_QUAD_AA || k == PROG_NODE_BOX6))) return -1;
     }
     return 0;
   }
@@ -409,7 +423,7 @@ struct CompiledProgram {
             const double pad = 1e-6 * (1.0 + std::max(fabs(lo[a]), fabs(hi[a])));
             g.lo[a] = lo[a] - pad; g.hi[a] = hi[a] + pad;
           }
-          u[0] = (uint64_t)RTX_NODE_MAKE(RTX_NODE_BOX, 0) | ((uint64_t)(p + PROG_BOX_UNITS + PROG_BOX6_UNITS) << 32);
+          u[0] = (uint64_t)RTX_NODE_MAKE(RTX_NODE_BOX, PROG_GUARD_IDX) | ((uint64_t)(p + PROG_BOX_UNITS + PROG_BOX6_UNITS) << 32);
           memcpy(u + 1, &g, sizeof(g));
           u += PROG_BOX_UNITS;
         }

@@ -55,8 +55,9 @@ struct Scene : rtx_scene_desc {
   uint32_t n_units;
   uint32_t tail_begin;  // first unit of the deferred section's program (0 = the world program has none); the units
                         // before it are all a walk with DEFER = true can reach
-  uint32_t tail_near_depth;  // > 0: the deferred section is a binary tree of boxes over static-sphere runs of this depth;
+  uint32_t tail_near_depth;  // > 0: the deferred section is a binary tree of boxes over leaf records, of this depth;
                              // walk_stream_near may walk it nearer child first
+  uint32_t head_near_depth;  // the same for the head section (its leaves may also hold BOX6 records and axis-aligned quads)
   uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
   uint32_t fresh_in_main;  // wavefront pipeline, with a head section: 1 = the head stream covers the survivors only and the
@@ -83,6 +84,8 @@ struct Scene : rtx_scene_desc {
 #define PROG_NODE_SYNC 10u       // wave rendezvous between top-level sections of the world program
 #define PROG_NODE_BOX6 11u       // the six axis-aligned faces of a box_new box (hits are reported as RTX_NODE_QUAD)
 #define PROG_NODE_MEDIUM_S 12u   // a constant medium whose boundary is one static sphere, evaluated in one step
+#define PROG_GUARD_IDX 0x0FFFFFFFu   // index field of the widened guard box in front of a BOX6 record (a box of the BVH
+                                     // carries the index of its bounds in the ABI's table)
 #define PROG_NODE_DEFER 13u      // behind the root box of the deferred section; aux = first unit of that section's program
 
 // Units a record occupies, from its header unit.
@@ -826,35 +829,47 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
   return true;
 }
 
-// walk_stream for a section that is a binary tree of boxes over runs of static spheres (the sphere cluster of the final
-// scene; the scene says whether its deferred section has that shape), with the NEARER child of every box walked first.
+// walk_stream for a section that is a binary tree of boxes (the sphere cluster and the ground of the final scene; the
+// scene says whether a section has that shape), with the NEARER child of every box walked first.  Leaves hold runs of
+// static spheres, axis-aligned quads and BOX6 records behind their guard boxes.
 // The reference walks left before right whatever the ray's direction (bvh.rs:94-102), so its tmax shrinks late; the
-// closest hit does not depend on the visiting order once ties are resolved the way the fixed order resolves them
-// (among hits with equal t the one that comes first in the program wins: a later sphere needs t < tmax, sphere.rs:99-101).
+// closest hit does not depend on the visiting order once ties are resolved the way the fixed order resolves them:
+// among hits with equal t the FIRST sphere of the program wins (a later one needs t < tmax, sphere.rs:99-101) and the
+// LAST quad (a later one needs only t <= tmax, quad.rs:74), and a quad beats a sphere.
 // What a different order can change is which boxes the shrinking tmax culls, and that matters only for a hit that lies
-// on the very boundary of its own box (a ray through one of the six extreme points of a sphere, to the last bit) and
-// ties with another hit at once: such a ray may find the other sphere.  The deterministic first-hit query keeps the
-// reference's order; this walk serves rendering, where paths are random and images agree in distribution.
+// on the very boundary of its own box (to the last bit) and ties with another hit at once: such a ray may find the
+// other primitive.  The deterministic first-hit query keeps the reference's order; this walk serves rendering, where
+// paths are random and images agree in distribution.
 //   stk: per-lane stack of unit positions (lane-private, stk[level * stk_stride]); depth = the tree's depth.
+//   root_single: the section starts with ONE box (its root) instead of the two children of a root tested elsewhere.
+//   QUADS: leaves may hold quads (otherwise static-sphere runs only, and the quad classes cost nothing).
 // Per lane: i = a box not tested yet (`single`: only it; otherwise it and its sibling, the two children of a box that
-// passed), or a sphere run of the leaf whose units end at `end`.
+// passed), or a unit of the leaf whose units end at `end`.
 #ifndef RT_NEAR_LEAF_BIAS
 #define RT_NEAR_LEAF_BIAS RT_STREAM_LEAF_BIAS
 #endif
 #ifndef RT_NEAR_REFILL
 #define RT_NEAR_REFILL RT_STREAM_REFILL
 #endif
-template <class Feed>
-RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride) {
-  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_BOX = 8, CL_DONE = 10 };
+template <bool QUADS, class Feed>
+RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single) {
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
   const double tmin = 0.001;
-  bool have = false, single = false;
+  bool have = false, single = false, best_quad = false;
   uint32_t id = 0, i = begin, end = 0xFFFFFFFFu, sp = 0, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
   uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
   double tmax = RT_INF;
   auto rs = feed.ray(0);
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  // a hit at t from the primitive at program position pos: does it replace the best one so far?
+  auto wins = [&](double t, uint32_t pos, bool quad) {
+    if (t < tmax) return true;
+    if (!(t == tmax)) return false;
+    if (!QUADS) return !best_quad && pos < best_pos;
+    if (quad != best_quad) return quad;              // a quad takes a tie from a sphere in either order
+    return quad ? pos > best_pos : pos < best_pos;
+  };
   for (;;) {
     if (have) {  // a lane whose units ran out takes the far child it left behind, or hands in its result
       const uint32_t k = RTX_NODE_KIND((uint32_t)unit);
@@ -869,7 +884,8 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         id = nid; rs = feed.ray(id);
         feed.start(id, tmax, hit_kind, hit_ctx);
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
-        cur = 0; i = begin; unit = prog[i]; have = true; single = false; end = 0xFFFFFFFFu; sp = 0; best_pos = 0;
+        cur = 0; i = begin; unit = prog[i]; have = true; single = root_single; end = 0xFFFFFFFFu; sp = 0;
+        best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;   // a hit from before the section: position 0
       }
     }
     if (!RT_WAVE_ANY(have)) {
@@ -882,6 +898,8 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
     if (!have || i >= end || kind == PROG_NODE_END || kind == PROG_NODE_SYNC) cls = CL_DONE;
     else if (kind == RTX_NODE_BOX) cls = CL_BOX;
     else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    else if (QUADS && kind == PROG_NODE_BOX6) cls = CL_BOX6;
+    else if (QUADS && kind == PROG_NODE_QUAD_AA) cls = CL_QUAD_AA;
     if (RT_WAVE_ANY(cls == CL_CHEAP)) {
       if (cls == CL_CHEAP) {
         uint32_t next;
@@ -897,31 +915,39 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
       }
       continue;
     }
-    const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_s = RT_WAVE_COUNT(cls == CL_SPHERE_S);
-    if (n_x > 0 && (n_s == 0 || n_x * RT_NEAR_LEAF_BIAS >= n_s)) {
+    const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_ss = RT_WAVE_COUNT(cls == CL_SPHERE_S);
+    const int n_b = QUADS ? RT_WAVE_COUNT(cls == CL_BOX6) : 0, n_a = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD_AA) : 0;
+    const int n_leaf = n_ss + n_b + n_a;
+    if (n_x > 0 && (n_leaf == 0 || n_x * RT_NEAR_LEAF_BIAS >= n_leaf)) {
       // box steps in a tight loop, while the lanes on boxes outweigh the lanes waiting on a leaf
       bool on_box = cls == CL_BOX;
       int nb, ns, nd;
       do {
         if (on_box) {
-          // the box at i, and unless `single` its sibling (the two children of the box this lane came through)
           const uint32_t c0 = i, c1 = (uint32_t)(unit >> 32);
-          const uint64_t u1 = single ? unit : prog[c1];
-          double e0 = 0.0, e1 = 0.0;
-          const bool p0 = slab_hit_entry((const double*)(prog + c0 + 1), lr, tmin, tmax, e0);
-          const bool p1 = !single && slab_hit_entry((const double*)(prog + c1 + 1), lr, tmin, tmax, e1);
-          RT_TRACE_STEP(RTX_NODE_BOX);
-          if (p0 || p1) {
-            const bool first0 = p0 && (!p1 || e0 <= e1);            // equal entries: the reference's order
-            if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
-            const uint32_t c = first0 ? c0 : c1;
-            end = (uint32_t)((first0 ? unit : u1) >> 32);
-            i = c + PROG_BOX_UNITS; unit = prog[i]; single = false;
-          } else if (sp > 0) {                                       // nothing here: on to the far child left behind
-            sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu;
+          if (QUADS && RTX_NODE_IDX((uint32_t)unit) == PROG_GUARD_IDX) {
+            // the guard in front of a BOX6 record: on to the record, or past it
+            const bool pass = slab_hit((const double*)(prog + c0 + 1), lr, tmin, tmax);
+            i = pass ? c0 + PROG_BOX_UNITS : c1; unit = prog[i < end ? i : begin];
           } else {
-            i = 0xFFFFFFFFu - 1u; end = 0u;                          // the section is done: the top of the loop hands in
+            // the box at i, and unless `single` its sibling (the two children of the box this lane came through)
+            const uint64_t u1 = single ? unit : prog[c1];
+            double e0 = 0.0, e1 = 0.0;
+            const bool p0 = slab_hit_entry((const double*)(prog + c0 + 1), lr, tmin, tmax, e0);
+            const bool p1 = !single && slab_hit_entry((const double*)(prog + c1 + 1), lr, tmin, tmax, e1);
+            if (p0 || p1) {
+              const bool first0 = p0 && (!p1 || e0 <= e1);            // equal entries: the reference's order
+              if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
+              const uint32_t c = first0 ? c0 : c1;
+              end = (uint32_t)((first0 ? unit : u1) >> 32);
+              i = c + PROG_BOX_UNITS; unit = prog[i]; single = false;
+            } else if (sp > 0) {                                       // nothing here: on to the far child left behind
+              sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu;
+            } else {
+              i = 0xFFFFFFFFu - 1u; end = 0u;                          // the section is done: the top of the loop hands in
+            }
           }
+          RT_TRACE_STEP(RTX_NODE_BOX);
         }
         const uint32_t k2 = RTX_NODE_KIND((uint32_t)unit);
         const bool fin = !have || i >= end || k2 == PROG_NODE_END || k2 == PROG_NODE_SYNC;
@@ -931,18 +957,53 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
       } while (nb > 0 && (ns == 0 || nb * RT_NEAR_LEAF_BIAS >= ns) && !(nd >= RT_NEAR_REFILL));
       continue;
     }
-    if (cls == CL_SPHERE_S) {
-      for (uint32_t k = 0; k < count; ++k) {
-        double t;
-        const DSphere sph = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
-        const uint32_t pos = (i << 6) + k + 1u;                      // program order of this sphere (0 = before the section)
-        if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && (t < tmax || pos < best_pos)) {
-          tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; best_pos = pos;
+    // leaves: the class most lanes wait for
+    int pick = CL_SPHERE_S, best_n = n_ss;
+    if (QUADS && n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
+    if (QUADS && n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+    uint32_t next = i;
+    if (pick == CL_SPHERE_S) {
+      if (cls == CL_SPHERE_S) {
+        for (uint32_t k = 0; k < count; ++k) {
+          double t;
+          const DSphere sph = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
+          const uint32_t pos = (i << 6) + k + 1u;                      // program order of this sphere (0 = before the section)
+          if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, false)) {
+            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; best_pos = pos; best_quad = false;
+          }
         }
+        RT_TRACE_STEP(32u + (uint32_t)CL_SPHERE_S);
+        next = i + 1 + PROG_SPHERE_S_UNITS * count;
       }
-      RT_TRACE_STEP(32u + (uint32_t)CL_SPHERE_S);
-      i = i + 1 + PROG_SPHERE_S_UNITS * count; unit = prog[i < end ? i : begin];
+    } else if (QUADS && pick == CL_BOX6) {
+      if (cls == CL_BOX6) {
+        const DBox6 bx = *(const DBox6*)(prog + i + 1);
+RT_UNROLL
+        for (int f = 0; f < 6; ++f) {
+          double t;
+          const uint32_t pos = (i << 6) + (uint32_t)f + 1u;
+          if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
+            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; best_pos = pos; best_quad = true;
+          }
+        }
+        RT_TRACE_STEP(32u + (uint32_t)CL_BOX6);
+        next = i + PROG_BOX6_UNITS;
+      }
+    } else if (QUADS) {
+      if (cls == CL_QUAD_AA) {
+        for (uint32_t k = 0; k < count; ++k) {
+          double t;
+          const DAAQuad qa = *(const DAAQuad*)(prog + i + 1 + PROG_QUAD_AA_UNITS * k);
+          const uint32_t pos = (i << 6) + k + 1u;
+          if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
+            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
+          }
+        }
+        RT_TRACE_STEP(32u + (uint32_t)CL_QUAD_AA);
+        next = i + 1 + PROG_QUAD_AA_UNITS * count;
+      }
     }
+    if (next != i) { i = next; unit = prog[i < end ? i : begin]; }
   }
 }
 

@@ -417,9 +417,9 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.ht = h.t; feed.hk = h.kind_idx; feed.hc = h.ctx;
   feed.work = TAIL ? &c->work_tail : &c->work_head; feed.n = n; feed.n_waves = gridDim.x * (blockDim.x / 64u); feed.lane = threadIdx.x & 63u;
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
-  if (NEAR) {  // the deferred section, nearer child first; the lanes' stacks sit behind the staged program
+  if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
-    walk_stream_near(S, prog, S.tail_begin, feed, stk, blockDim.x);
+    walk_stream_near<!TAIL>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
   } else {
     walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
   }
@@ -1118,11 +1118,20 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const bool stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
   // The deferred section nearer child first (walk_stream_near), when it has the shape for it: RTX_WF_NEAR=0 keeps the
   // reference's left-to-right order.  Each lane's stack (one unit position per tree level) lives in LDS.
+  // RTX_WF_NEAR=2 walks the head section that way too.  Not the default: on the final scene the ground's 400 boxes
+  // gain nothing from it (10 sample rows: 2004 and 2026 Msamples/s in the fixed order against 1957 and 1963) - most
+  // rays meet the ground from above and the first box they enter holds their hit in either order, while the walk pays
+  // for two box tests per step and the stack.
   const char* near_env = getenv("RTX_WF_NEAR");
-  const bool near_ok = stream_tail && sc->dev.tail_near_depth > 0 && !(near_env && atoi(near_env) == 0);
+  const int near_mode = near_env ? atoi(near_env) : 1;
+  const bool near_ok = stream_tail && sc->dev.tail_near_depth > 0 && near_mode != 0;
   const size_t near_stack_bytes = (size_t)sc->dev.tail_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
   const bool near_lds = near_ok && tail_lds && tail_bytes + near_stack_bytes <= kLdsBudget;
   const bool near_global = near_ok && !tail_lds && near_stack_bytes <= kLdsBudget;
+  const bool near_head_ok = stream_head && sc->dev.head_near_depth > 0 && near_mode == 2;
+  const size_t near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
+  const bool near_head_lds = near_head_ok && head_lds && head_bytes + near_head_stack <= kLdsBudget;
+  const bool near_head_global = near_head_ok && !head_lds && near_head_stack <= kLdsBudget;
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   Scene dev = sc->dev;
   dev.head_end = head_end;
@@ -1183,7 +1192,11 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
         if (head_end) {  // the head section of the world program, streamed
           TimedSpan sh;
           const bool timed_head = span_begin(ctx, s, sh, 3);
-          if (head_lds)
+          if (near_head_lds)
+            hipLaunchKernelGGL((k_wf_stream<true, false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes + near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (near_head_global)
+            hipLaunchKernelGGL((k_wf_stream<false, false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (head_lds)
             hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else
             hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
@@ -1298,7 +1311,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);

@@ -164,12 +164,13 @@ def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
     scene.close()
 
 
-@pytest.mark.parametrize("near", ["0", "1"])
-def test_deferred_section_nearer_child_first_traces_the_same_paths(gpu_ctx, monkeypatch, near):
-    """The deferred sphere cluster of the final scene is a binary tree of boxes over sphere runs; by default the stream
-    walks the nearer child of every box first (RTX_WF_NEAR=0: the reference's left-to-right order).  The closest hit
-    does not depend on the visiting order (ties go to the earlier sphere of the program either way), so both must
-    trace the fused pipeline's paths, which walks in the reference's order."""
+@pytest.mark.parametrize("near", ["0", "1", "2"])
+def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, near):
+    """The ground of the final scene (head section) and its sphere cluster (deferred section) are binary trees of boxes
+    over BOX6 records and sphere runs; their streams can walk the nearer child of every box first (RTX_WF_NEAR=0: the
+    reference's left-to-right order in both, 1, the default: nearer first in the deferred section, 2: in both).  The closest
+    hit does not depend on the visiting order (ties are resolved as the fixed order resolves them), so all must trace
+    the fused pipeline's paths, which walks in the reference's order."""
     gp = rt.Graph()
     wp, lp, cam = scenes.build("final", gp, width=240, spp=16, depth=30)
     scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
