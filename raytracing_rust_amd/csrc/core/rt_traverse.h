@@ -853,6 +853,7 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 #endif
 template <bool QUADS, class Feed>
 RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single) {
+  (void)S;
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
   const double tmin = 0.001;
   bool have = false, single = false, best_quad = false;

@@ -111,9 +111,12 @@ def hostsim_first_hit(desc, rays):
     return out
 
 
-def hostsim_first_hit_staged(desc, rays):
+def hostsim_first_hit_staged(desc, rays, near=0):
     """First hits through the stages of the wavefront pipeline (streamed head section, rest of the world program,
-    streamed deferred section).  Returns (aov dict, number of rays that went through a stream walk)."""
+    streamed deferred section).  Returns (aov dict, number of rays that went through a stream walk).
+    near: 1 = the deferred section nearer child first, 2 = the head section too (hostsim_lib().sim_near_walks()
+    tells how many sections were walked that way)."""
+    hostsim_lib().sim_set_near(near)
     r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
     n = r.shape[0]
     out = {"t": np.empty(n), "normal": np.empty((n, 3)), "prim_id": np.empty(n, dtype=np.uint32),
@@ -121,6 +124,7 @@ def hostsim_first_hit_staged(desc, rays):
     k = hostsim_lib().sim_first_hit_staged(C.byref(desc), dptr(r), n, dptr(out["t"]), dptr(out["normal"]),
                                            out["prim_id"].ctypes.data_as(PU32), out["mat_id"].ctypes.data_as(PU32),
                                            out["front"].ctypes.data_as(PU8))
+    hostsim_lib().sim_set_near(0)
     return out, k
 
 

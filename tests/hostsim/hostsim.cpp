@@ -18,6 +18,8 @@ static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 using namespace rt;
 
 static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true;  // compile options under test
+static int g_near_walks = 0;
+static int g_near = 0;  // staged walk: 1 = the deferred section nearer child first, 2 = the head section too
 
 extern "C" {
 
@@ -79,10 +81,12 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   if (!S.head_end && !S.tail_begin) return -1;
   std::vector<Hit> hits(n);
   std::vector<uint32_t> deferred;
-  int streamed = 0;
+  int streamed = 0, near_walks = 0;
   if (S.head_end) {
     HostFeed feed{rays, nullptr, n, 0, hits.data(), false};
-    walk_stream(S, S.prog, S.world_begin, feed);
+    std::vector<uint32_t> stk(S.head_near_depth + 1u);
+    if (g_near == 2 && S.head_near_depth > 0) { walk_stream_near<true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1; }
+    else walk_stream(S, S.prog, S.world_begin, feed);
     streamed += (int)n;
   }
   for (size_t i = 0; i < n; ++i) {
@@ -98,7 +102,9 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   }
   if (S.tail_begin) {
     HostFeed feed{rays, deferred.data(), deferred.size(), 0, hits.data(), true};
-    walk_stream(S, S.prog, S.tail_begin, feed);
+    std::vector<uint32_t> stk(S.tail_near_depth + 1u);
+    if (g_near >= 1 && S.tail_near_depth > 0) { walk_stream_near<false>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
+    else walk_stream(S, S.prog, S.tail_begin, feed);
     streamed += (int)deferred.size();
   }
   for (size_t i = 0; i < n; ++i) {
@@ -114,9 +120,12 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
     if (mat_id) mat_id[i] = any ? sf.mat : 0xFFFFFFFFu;
     if (front) front[i] = any ? (sf.front ? 1 : 0) : 0;
   }
+  g_near_walks = near_walks;
   return streamed;
 }
 
+void sim_set_near(int mode) { g_near = mode; }
+int sim_near_walks(void) { return g_near_walks; }   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }

@@ -122,3 +122,33 @@ def large_bvh_beyond_lds(g):
 
 ALL = [flat_random_prims, bvh_mixed_leaves, nested_transforms, ties_edges_and_axis_parallel, empty_lists_and_media,
        large_bvh_beyond_lds]
+
+
+def ties_in_box_trees(g):
+    """The shapes of the final scene's head and deferred sections with many hits of exactly equal t: a ground of 8 x 8
+    boxes and 16 floating axis-aligned quads, each quad there twice (different materials), in one BVH; a light; a
+    translated BVH of 64 overlapping spheres, half of them there twice.  Which of two coincident primitives a ray
+    reports is decided by the order of the walk (the first sphere, the last quad)."""
+    rng = np.random.default_rng(107)
+    mats = _materials(g)
+    leaves = []
+    for i in range(8):
+        for j in range(8):
+            h = float(rng.uniform(5.0, 25.0))
+            leaves.append(g.box((-80.0 + 20.0 * i, 0.0, -80.0 + 20.0 * j), (-61.0 + 20.0 * i, h, -61.0 + 20.0 * j), mats[0]))
+    for i in range(4):
+        for j in range(4):
+            q = (-70.0 + 40.0 * i, 40.0 + 3.0 * ((i + j) % 3), -70.0 + 40.0 * j)
+            leaves.append(g.quad(q, (25.0, 0, 0), (0, 0, 25.0), mats[0]))
+            leaves.append(g.quad(q, (25.0, 0, 0), (0, 0, 25.0), mats[1]))
+    order = rng.permutation(len(leaves))
+    ground = g.bvh(g.list([leaves[k] for k in order]))
+    centres = [tuple(c) for c in rng.uniform(0.0, 60.0, size=(64, 3))]
+    centres += centres[:32]
+    spheres = [g.sphere(c, 9.0, mats[k % 3]) for k, c in enumerate(centres)]
+    cluster = g.translate(g.bvh(g.list(spheres)), (-30.0, 60.0, -30.0))
+    world = g.list([ground, g.quad((-20, 200, -20), (40, 0, 0), (0, 0, 40), mats[3]), cluster])
+    at_quads = _rays_towards(rng, 3000, np.array([0.0, 43.0, 0.0]), 80.0, 300.0)
+    at_cluster = _rays_towards(rng, 3000, np.array([0.0, 90.0, 0.0]), 30.0, 250.0)
+    inside = np.concatenate([rng.uniform([-30.0, 60.0, -30.0], [30.0, 120.0, 30.0], (2000, 3)), rng.normal(size=(2000, 3)), rng.uniform(0, 1, (2000, 1))], axis=1)
+    return world, None, np.concatenate([at_quads, at_cluster, inside, _rays_towards(rng, 3000, np.array([0.0, 50.0, 0.0]), 90.0, 300.0)])

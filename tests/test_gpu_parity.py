@@ -186,12 +186,18 @@ def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, 
     scene.close()
 
 
-@pytest.mark.parametrize("recipe", [recipes.large_bvh_beyond_lds, recipes.empty_lists_and_media, recipes.nested_transforms],
-                         ids=lambda r: r.__name__)
-def test_pipelines_agree_on_recipes(gpu_ctx, recipe):
+@pytest.mark.parametrize("recipe,near", [(recipes.large_bvh_beyond_lds, None), (recipes.empty_lists_and_media, None),
+                                         (recipes.nested_transforms, None), (recipes.ties_in_box_trees, None),
+                                         (recipes.ties_in_box_trees, "2")],
+                         ids=lambda v: getattr(v, "__name__", v))
+def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
     """The same identical-paths check on graphs the shipped scenes do not have: a program too large for LDS (global
     memory walk, deferred box BVH), generic (box-bounded, transformed) media next to sphere-bounded ones, nested
-    transforms.  The frame is 97 x 61 so that the 8 x 8 tiles are clipped on both edges."""
+    transforms, box trees full of coincident quads and spheres (walked nearer child first in the deferred section,
+    and with RTX_WF_NEAR=2 in the head section as well).  The frame is 97 x 61 so that the 8 x 8 tiles are clipped on
+    both edges."""
+    if near is not None:
+        monkeypatch.setenv("RTX_WF_NEAR", near)
     gp = rt.Graph()
     wp, _, _ = recipe(gp)
     cam = rt.initialize_camera(rt.camera_desc(aspect_ratio=97.0 / 61.0, image_width=97, samples_per_pixel=9, max_depth=12,
