@@ -45,6 +45,7 @@ struct CompiledProgram {
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
   uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes of this depth (walk_stream_near's shape)
   uint32_t head_near_depth = 0;    // > 0: so is the head section under its root box
+  uint32_t tail_near_quads = 0;    // the deferred section's leaves hold quads (it needs the walk's quad classes)
   uint32_t defer_pos = 0;          // unit index of the DEFER unit
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
@@ -86,7 +87,9 @@ struct CompiledProgram {
     } else {
       world_begin = emit_range(d, d.world_begin, d.world_end, true);
     }
-    tail_near_depth = tail_begin ? near_depth_of_tail() : 0u;
+    tail_near_quads = 0;
+    tail_near_depth = tail_begin ? near_depth_of_tail(false) : 0u;
+    if (tail_begin && tail_near_depth == 0) { tail_near_depth = near_depth_of_tail(true); tail_near_quads = tail_near_depth ? 1u : 0u; }
     if (split_head) find_head(d);
     head_near_depth = 0;
     if (head_end) {
@@ -105,15 +108,15 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
-    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
+    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
     return S;
   }
 
  private:
   // Depth of the deferred section if it has the shape walk_stream_near needs: behind leading ENTER/NOP units, every
   // box is followed either by exactly two box subtrees that fill it, or by leaf records only: static-sphere runs, and
-  // with `quads` (the head section) axis-aligned quads and BOX6 records behind their guards.  0 = another shape.
-  uint32_t near_depth_of_tail() const {
+  // with `quads` also quads (general ones, axis-aligned runs) and BOX6 records behind their guards.  0 = another shape.
+  uint32_t near_depth_of_tail(bool quads) const {
     uint32_t pos = tail_begin;
     const uint32_t n = (uint32_t)units.size();
     while (pos < n) {
@@ -123,7 +126,7 @@ struct CompiledProgram {
     uint32_t end = pos;
     while (end < n && RTX_NODE_KIND((uint32_t)units[end]) != PROG_NODE_END) end += prog_record_units(units[end]);
     if (end >= n) return 0;
-    const int dpt = near_depth(pos, end, 0, false);
+    const int dpt = near_depth(pos, end, 0, quads);
     return dpt > 0 ? (uint32_t)dpt : 0u;
   }
   int near_depth(uint32_t pos, uint32_t end, int level, bool quads) const {   // -1: not the shape
@@ -143,7 +146,7 @@ struct CompiledProgram {
             (uint32_t)(units[p] >> 32) != rec + PROG_BOX6_UNITS) return -1;
         continue;
       }
-      if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP && !(quads && (k == PROG_NODE_QUAD_AA || k == PROG_NODE_BOX6))) return -1;
+      if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP && !(quads && (k == PROG_NODE_QUAD_AA || k == PROG_NODE_BOX6 || k == RTX_NODE_QUAD))) return -1;
     }
     return 0;
   }

@@ -57,7 +57,9 @@ struct Scene : rtx_scene_desc {
                         // before it are all a walk with DEFER = true can reach
   uint32_t tail_near_depth;  // > 0: the deferred section is a binary tree of boxes over leaf records, of this depth;
                              // walk_stream_near may walk it nearer child first
-  uint32_t head_near_depth;  // the same for the head section (its leaves may also hold BOX6 records and axis-aligned quads)
+  uint32_t head_near_depth;  // the same for the head section (its leaves may also hold quads and BOX6 records)
+  uint32_t tail_near_quads;  // the deferred section's leaves hold quads too (0: static-sphere runs only)
+  uint32_t _pad_near;
   uint32_t head_end;    // the SYNC unit that ends the head section (0 = none): the world program starts with one large
                         // box subtree, which may be walked as a stream (walk_stream) before the rest of the program
   uint32_t fresh_in_main;  // wavefront pipeline, with a head section: 1 = the head stream covers the survivors only and the
@@ -831,7 +833,7 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 
 // walk_stream for a section that is a binary tree of boxes (the sphere cluster and the ground of the final scene; the
 // scene says whether a section has that shape), with the NEARER child of every box walked first.  Leaves hold runs of
-// static spheres, axis-aligned quads and BOX6 records behind their guard boxes.
+// static spheres, quads (axis-aligned runs or single general ones) and BOX6 records behind their guard boxes.
 // The reference walks left before right whatever the ray's direction (bvh.rs:94-102), so its tmax shrinks late; the
 // closest hit does not depend on the visiting order once ties are resolved the way the fixed order resolves them:
 // among hits with equal t the FIRST sphere of the program wins (a later one needs t < tmax, sphere.rs:99-101) and the
@@ -853,8 +855,7 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 #endif
 template <bool QUADS, class Feed>
 RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single) {
-  (void)S;
-  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_QUAD = 4, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
   const double tmin = 0.001;
   bool have = false, single = false, best_quad = false;
   uint32_t id = 0, i = begin, end = 0xFFFFFFFFu, sp = 0, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
@@ -899,8 +900,9 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
     if (!have || i >= end || kind == PROG_NODE_END || kind == PROG_NODE_SYNC) cls = CL_DONE;
     else if (kind == RTX_NODE_BOX) cls = CL_BOX;
     else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
-    else if (QUADS && kind == PROG_NODE_BOX6) cls = CL_BOX6;
-    else if (QUADS && kind == PROG_NODE_QUAD_AA) cls = CL_QUAD_AA;
+    else if (QUADS && kind == PROG_NODE_BOX6) cls = (lr.skip & 8u) ? CL_QUAD : CL_BOX6;   // as in walk_stream
+    else if (QUADS && kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
+    else if (QUADS && kind == RTX_NODE_QUAD) cls = CL_QUAD;
     if (RT_WAVE_ANY(cls == CL_CHEAP)) {
       if (cls == CL_CHEAP) {
         uint32_t next;
@@ -917,8 +919,8 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
       continue;
     }
     const int n_x = RT_WAVE_COUNT(cls == CL_BOX), n_ss = RT_WAVE_COUNT(cls == CL_SPHERE_S);
-    const int n_b = QUADS ? RT_WAVE_COUNT(cls == CL_BOX6) : 0, n_a = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD_AA) : 0;
-    const int n_leaf = n_ss + n_b + n_a;
+    const int n_b = QUADS ? RT_WAVE_COUNT(cls == CL_BOX6) : 0, n_a = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD_AA) : 0, n_q = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD) : 0;
+    const int n_leaf = n_ss + n_b + n_a + n_q;
     if (n_x > 0 && (n_leaf == 0 || n_x * RT_NEAR_LEAF_BIAS >= n_leaf)) {
       // box steps in a tight loop, while the lanes on boxes outweigh the lanes waiting on a leaf
       bool on_box = cls == CL_BOX;
@@ -962,6 +964,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
     int pick = CL_SPHERE_S, best_n = n_ss;
     if (QUADS && n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
     if (QUADS && n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+    if (QUADS && n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
     uint32_t next = i;
     if (pick == CL_SPHERE_S) {
       if (cls == CL_SPHERE_S) {
@@ -989,6 +992,21 @@ RT_UNROLL
         }
         RT_TRACE_STEP(32u + (uint32_t)CL_BOX6);
         next = i + PROG_BOX6_UNITS;
+      }
+    } else if (QUADS && pick == CL_QUAD) {
+      if (cls == CL_QUAD) {   // quads through the ABI's table: general ones, and compact records when the ray is not finite
+        uint32_t cnt = 1u, size = 1u;
+        if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
+        else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
+        for (uint32_t k = 0; k < cnt; ++k) {
+          double t;
+          const uint32_t pos = (i << 6) + k + 1u;
+          if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
+            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
+          }
+        }
+        RT_TRACE_STEP(32u + (uint32_t)CL_QUAD);
+        next = i + size;
       }
     } else if (QUADS) {
       if (cls == CL_QUAD_AA) {

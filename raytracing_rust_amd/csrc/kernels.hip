@@ -396,7 +396,7 @@ struct QueueFeed {
   __device__ void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { ht[id] = tmax; hk[id] = kind; hc[id] = ctx; }
 };
 
-template <bool USE_LDS, bool TAIL, bool NEAR = false>
+template <bool USE_LDS, bool TAIL, int NEAR = 0>   // NEAR: 1 = nearer child first over sphere leaves, 2 = quads in the leaves too
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t cap, WfCounters* c, WfQueue q, WfHits h,
                                                     const uint32_t* __restrict__ defer_list) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
   if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
-    walk_stream_near<!TAIL>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
+    walk_stream_near<NEAR == 2>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
   } else {
     walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
   }
@@ -1116,19 +1116,22 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const bool tail_lds = tail_bytes <= kLdsBudget;
   const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
   const bool stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
-  // The deferred section nearer child first (walk_stream_near), when it has the shape for it: RTX_WF_NEAR=0 keeps the
-  // reference's left-to-right order.  Each lane's stack (one unit position per tree level) lives in LDS.
-  // RTX_WF_NEAR=2 walks the head section that way too.  Not the default: on the final scene the ground's 400 boxes
-  // gain nothing from it (10 sample rows: 2004 and 2026 Msamples/s in the fixed order against 1957 and 1963) - most
-  // rays meet the ground from above and the first box they enter holds their hit in either order, while the walk pays
-  // for two box tests per step and the stack.
+  // Sections that are binary trees of boxes over leaf records can be walked nearer child first (walk_stream_near);
+  // each lane's stack (one unit position per tree level) lives in LDS.  By default (RTX_WF_NEAR=1) the deferred
+  // section is, and the head section when it is too large for LDS: the stress scene's BVH of 1 M spheres and quads
+  // (20 levels, walked from global memory) goes from 49.6 to 76.9 Msamples/s, while the 400 boxes of the final
+  // scene's ground are slower that way (10 sample rows: 1957 and 1963 Msamples/s against 2004 and 2026 in the fixed
+  // order; most rays meet the ground from above, the first box they enter holds their hit in either order, and the
+  // walk pays for two box tests per step and the stack).  RTX_WF_NEAR=0 keeps the reference's left-to-right order
+  // everywhere, 2 walks every section of the shape nearer child first.
   const char* near_env = getenv("RTX_WF_NEAR");
   const int near_mode = near_env ? atoi(near_env) : 1;
   const bool near_ok = stream_tail && sc->dev.tail_near_depth > 0 && near_mode != 0;
   const size_t near_stack_bytes = (size_t)sc->dev.tail_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
   const bool near_lds = near_ok && tail_lds && tail_bytes + near_stack_bytes <= kLdsBudget;
   const bool near_global = near_ok && !tail_lds && near_stack_bytes <= kLdsBudget;
-  const bool near_head_ok = stream_head && sc->dev.head_near_depth > 0 && near_mode == 2;
+  const bool near_quads = sc->dev.tail_near_quads != 0;
+  const bool near_head_ok = stream_head && sc->dev.head_near_depth > 0 && (near_mode == 2 || (near_mode == 1 && !head_lds));
   const size_t near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
   const bool near_head_lds = near_head_ok && head_lds && head_bytes + near_head_stack <= kLdsBudget;
   const bool near_head_global = near_head_ok && !head_lds && near_head_stack <= kLdsBudget;
@@ -1193,9 +1196,9 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
           TimedSpan sh;
           const bool timed_head = span_begin(ctx, s, sh, 3);
           if (near_head_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes + near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
+            hipLaunchKernelGGL((k_wf_stream<true, false, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes + near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (near_head_global)
-            hipLaunchKernelGGL((k_wf_stream<false, false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
+            hipLaunchKernelGGL((k_wf_stream<false, false, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (head_lds)
             hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else
@@ -1206,10 +1209,14 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
         if (tail_begin) {  // the deferred section for the rays that passed its root box
           TimedSpan st;
           const bool timed_tail = span_begin(ctx, s, st, 2);
-          if (stream_tail && near_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          if (stream_tail && near_lds && near_quads)
+            hipLaunchKernelGGL((k_wf_stream<true, true, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (stream_tail && near_lds)
+            hipLaunchKernelGGL((k_wf_stream<true, true, 1>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+          else if (stream_tail && near_global && near_quads)
+            hipLaunchKernelGGL((k_wf_stream<false, true, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (stream_tail && near_global)
-            hipLaunchKernelGGL((k_wf_stream<false, true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
+            hipLaunchKernelGGL((k_wf_stream<false, true, 1>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (stream_tail && tail_lds)
             hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
           else if (stream_tail)
@@ -1311,7 +1318,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);

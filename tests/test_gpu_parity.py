@@ -30,7 +30,8 @@ def test_first_hit_aov_bit_exact_named_scenes(gpu_ctx, name, width):
 
 def test_first_hit_aov_bit_exact_stress_scene(gpu_ctx):
     """The synthetic stress configuration at 200 000 primitives (a 13 MB hit program, walked from global memory):
-    first hits bit-exact against the oracle's recursive BVH, and both pipelines trace the same paths through it."""
+    first hits bit-exact against the oracle's recursive BVH, and both pipelines trace the same paths through it (the
+    wavefront pipeline walks this BVH, its head section, nearer child first; the fused one in the reference's order)."""
     go, wo, lo, gp, wp, lp, cam = _pair("stress", width=480, spp=4, depth=12, n_prims=200000)
     scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
     rays = rt.pixel_center_rays(cam, time=0.5)
@@ -42,7 +43,7 @@ def test_first_hit_aov_bit_exact_stress_scene(gpu_ctx):
         gpu_ctx.reset_stats()
         out[pipe] = (scene.render(cam, rt.render_opts(cam, seed=9, pipeline=pipe)), gpu_ctx.stats())
     (a, sa), (b, sb) = out[_capi.PIPELINE_FUSED], out[_capi.PIPELINE_WAVEFRONT]
-    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"] and sb["head_launches"] > 0
     np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
     scene.close()
 
@@ -168,7 +169,8 @@ def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
 def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, near):
     """The ground of the final scene (head section) and its sphere cluster (deferred section) are binary trees of boxes
     over BOX6 records and sphere runs; their streams can walk the nearer child of every box first (RTX_WF_NEAR=0: the
-    reference's left-to-right order in both, 1, the default: nearer first in the deferred section, 2: in both).  The closest
+    reference's left-to-right order in both; 1, the default: nearer first in the deferred section, and in a head section
+    too large for LDS; 2: in both).  The closest
     hit does not depend on the visiting order (ties are resolved as the fixed order resolves them), so all must trace
     the fused pipeline's paths, which walks in the reference's order."""
     gp = rt.Graph()

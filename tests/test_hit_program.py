@@ -70,7 +70,7 @@ def test_staged_walk_with_streamed_sections_is_the_same_walk(name, width):
     assert np.isfinite(whole["t"]).sum() > 1000
 
 
-@pytest.mark.parametrize("name", ["final", "ties"])
+@pytest.mark.parametrize("name", ["final", "ties", "stress"])
 def test_nearer_child_first_finds_the_same_hits(name):
     """Box trees of the head and deferred sections walked nearer child first (walk_stream_near) against the reference's
     fixed left-to-right order (bvh.rs:94-102): the same first hit, bit for bit, down to which of several primitives
@@ -84,17 +84,22 @@ def test_nearer_child_first_finds_the_same_hits(name):
         sec = np.concatenate([rng.uniform([-1000.0, 0.0, -1000.0], [1000.0, 600.0, 1000.0], (8000, 3)), rng.normal(size=(8000, 3)),
                               rng.uniform(0, 1, (8000, 1))], axis=1)
         rays = np.concatenate([rt.pixel_center_rays(cam, time=0.7), sec])
+    elif name == "stress":   # one BVH over spheres and general quads: it is the head section, nothing is deferred
+        wp, lp, cam = scenes.build("stress", gp, width=160, n_prims=30000)
+        rng = np.random.default_rng(32)
+        sec = np.concatenate([rng.uniform(-1000.0, 1000.0, (8000, 3)), rng.normal(size=(8000, 3)), rng.uniform(0, 1, (8000, 1))], axis=1)
+        rays = np.concatenate([rt.pixel_center_rays(cam, time=0.2), sec])
     else:
         wp, lp, rays = recipes.ties_in_box_trees(gp)
     d = rt.flatten(gp, wp, lp)
     whole = H.hostsim_first_hit(d, rays)
-    for near, walks in ((1, 1), (2, 2)):
+    for near, walks in ((1, 0 if name == "stress" else 1), (2, 1 if name == "stress" else 2)):
         staged, streamed = H.hostsim_first_hit_staged(d, rays, near=near)
         assert H.hostsim_lib().sim_near_walks() == walks
         H.assert_aov_equal(whole, staged, f"{name} near={near}")
-        assert streamed > len(rays)
+        assert streamed >= len(rays)
     hit = np.isfinite(whole["t"])
-    assert hit.sum() > 2000
+    assert hit.sum() > 1500
     if name == "ties":   # both copies of the doubled quads and spheres do win somewhere?  No: always the same copy
         ids = set(np.unique(whole["prim_id"][hit]).tolist())
         quads = [6 * 64 + 2 * k for k in range(16)]              # creation ordinals: 64 boxes of six faces, then the quad pairs
