@@ -845,6 +845,7 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 //   stk: per-lane stack of unit positions (lane-private, stk[level * stk_stride]); depth = the tree's depth.
 //   root_single: the section starts with ONE box (its root) instead of the two children of a root tested elsewhere.
 //   QUADS: leaves may hold quads (otherwise static-sphere runs only, and the quad classes cost nothing).
+//   AHEAD: see the box step.
 // Per lane: i = a box not tested yet (`single`: only it; otherwise it and its sibling, the two children of a box that
 // passed), or a unit of the leaf whose units end at `end`.
 #ifndef RT_NEAR_LEAF_BIAS
@@ -853,7 +854,7 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 #ifndef RT_NEAR_REFILL
 #define RT_NEAR_REFILL RT_STREAM_REFILL
 #endif
-template <bool QUADS, class Feed>
+template <bool QUADS, bool AHEAD, class Feed>
 RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single) {
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_QUAD = 4, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
   const double tmin = 0.001;
@@ -935,6 +936,11 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
           } else {
             // the box at i, and unless `single` its sibling (the two children of the box this lane came through)
             const uint64_t u1 = single ? unit : prog[c1];
+            // AHEAD: the units behind both boxes are read together with the bounds; the walk goes on with one of them
+            // (the image is padded past its END).  It pays a little for a program in LDS (one dependent read less per
+            // level: final scene 2257-2265 -> 2268-2289 Msamples/s over repeated runs), not for one in global memory,
+            // where the unit behind the box that is not taken is one more cache line to fetch (stress scene 79.3 -> 72.7).
+            const uint64_t n0 = AHEAD ? prog[c0 + PROG_BOX_UNITS] : 0ull, n1 = (AHEAD && !single) ? prog[c1 + PROG_BOX_UNITS] : n0;
             double e0 = 0.0, e1 = 0.0;
             const bool p0 = slab_hit_entry((const double*)(prog + c0 + 1), lr, tmin, tmax, e0);
             const bool p1 = !single && slab_hit_entry((const double*)(prog + c1 + 1), lr, tmin, tmax, e1);
@@ -943,7 +949,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
               if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
               const uint32_t c = first0 ? c0 : c1;
               end = (uint32_t)((first0 ? unit : u1) >> 32);
-              i = c + PROG_BOX_UNITS; unit = prog[i]; single = false;
+              i = c + PROG_BOX_UNITS; unit = AHEAD ? (first0 ? n0 : n1) : prog[i]; single = false;
             } else if (sp > 0) {                                       // nothing here: on to the far child left behind
               sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu;
             } else {

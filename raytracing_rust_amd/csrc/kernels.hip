@@ -134,7 +134,7 @@ __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
 
 // One thread: decide how many new camera paths top the queue up and flip the in/out roles.  New paths take the
 // slots behind the survivors, so the ray generation kernel needs no atomics.
-__global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, unsigned long long* __restrict__ stats) {
+__global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, unsigned long long* __restrict__ stats, int count_segments) {
   const uint32_t survivors = c->finished ? 0u : c->n_out;
   c->finished = 0;
   wf_flush_timing(c);
@@ -149,6 +149,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->n_out = 0;
   c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
   if (g) atomicAdd(&stats[0], (unsigned long long)g);  // two pipelines may be preparing at the same time
+  if (count_segments && survivors + g) atomicAdd(&stats[1], (unsigned long long)(survivors + g));  // no world-program launch will
 }
 
 // Ray generation (Camera::get_ray, camera.rs:133-164): path index -> (sample, pixel), pixels enumerated tile by tile
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
   if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
-    walk_stream_near<NEAR == 2>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
+    walk_stream_near<NEAR == 2, USE_LDS>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
   } else {
     walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
   }
@@ -850,6 +851,7 @@ struct rtx_scene {
   rtx_context* ctx = nullptr;
   Scene dev;  // device pointers
   uint32_t n_general_media = 0;  // media of the world program whose boundary is a program of its own
+  bool nothing_behind_head = false;  // the world program holds nothing but its head section (no unit behind it tests anything)
   const uint8_t* mat_class = nullptr;  // per material: the class (MC_*) the shading kernel sorts hits by
   std::vector<void*> allocs;
 };
@@ -1157,6 +1159,9 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // without a head section every path starts at the start of the program anyway: the kernel only has to make the rays
   if (head_end == 0 && main_lds && !(fresh_env && (atoi(fresh_env) == 0 || atoi(fresh_env) == 1))) dev.fresh_in_main = 2u;
   const bool gen_in_main = dev.fresh_in_main == 2u;   // then main_lds holds (the whole world program fits LDS)
+  // A world that is one large BVH is all head section: the head stream leaves every path's closest hit in the hit
+  // arrays, and a world-program launch would only read and rewrite them (stress scene: 23 % of the GPU time).
+  const bool skip_main = head_end != 0 && dev.fresh_in_main == 0u && sc->nothing_behind_head;
   auto k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
               : main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
                          : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
@@ -1190,7 +1195,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       hipStream_t s = r.s;
       for (int it = 0; it < chunk; ++it) {
         WfQueue qin = L.q[r.cur], qout = L.q[r.cur ^ 1];
-        hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, L.c, cap, r.fr.per_sample, ctx->d_counters);
+        hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, L.c, cap, r.fr.per_sample, ctx->d_counters, skip_main ? 1 : 0);
         if (dev.fresh_in_main != 2u) hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, s, *cam, r.fr, seed, cap, L.c, qin);
         if (head_end) {  // the head section of the world program, streamed
           TimedSpan sh;
@@ -1205,7 +1210,8 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
             hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
           if (timed_head) span_end(ctx, s, sh);
         }
-        hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
+        if (!skip_main)
+          hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
         if (tail_begin) {  // the deferred section for the rays that passed its root box
           TimedSpan st;
           const bool timed_tail = span_begin(ctx, s, st, 2);
@@ -1320,6 +1326,16 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
   sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
   sc->n_general_media = prog.n_general_media;
+  sc->nothing_behind_head = false;
+  if (prog.head_end && !prog.tail_begin && d->n_media == 0) {
+    bool nothing = true;
+    for (uint32_t i = prog.head_end; i < (uint32_t)prog.units.size() && nothing; i += rt::prog_record_units(prog.units[i])) {
+      const uint32_t k = RTX_NODE_KIND((uint32_t)prog.units[i]);
+      if (k == PROG_NODE_END) break;
+      nothing = k == PROG_NODE_SYNC || k == PROG_NODE_NOP || k == RTX_NODE_ENTER || k == RTX_NODE_EXIT;
+    }
+    sc->nothing_behind_head = nothing;
+  }
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)

@@ -85,7 +85,7 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   if (S.head_end) {
     HostFeed feed{rays, nullptr, n, 0, hits.data(), false};
     std::vector<uint32_t> stk(S.head_near_depth + 1u);
-    if (g_near == 2 && S.head_near_depth > 0) { walk_stream_near<true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1; }
+    if (g_near == 2 && S.head_near_depth > 0) { walk_stream_near<true, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1; }
     else walk_stream(S, S.prog, S.world_begin, feed);
     streamed += (int)n;
   }
@@ -103,8 +103,8 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   if (S.tail_begin) {
     HostFeed feed{rays, deferred.data(), deferred.size(), 0, hits.data(), true};
     std::vector<uint32_t> stk(S.tail_near_depth + 1u);
-    if (g_near >= 1 && S.tail_near_depth > 0 && S.tail_near_quads) { walk_stream_near<true>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
-    else if (g_near >= 1 && S.tail_near_depth > 0) { walk_stream_near<false>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
+    if (g_near >= 1 && S.tail_near_depth > 0 && S.tail_near_quads) { walk_stream_near<true, false>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
+    else if (g_near >= 1 && S.tail_near_depth > 0) { walk_stream_near<false, true>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
     else walk_stream(S, S.prog, S.tail_begin, feed);
     streamed += (int)deferred.size();
   }
