@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
                                                   const uint8_t* __restrict__ mat_class) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n = c->n_in;
+  // a queue of n entries has no more than n / RT_SHADE_CHUNK + 1 chunks to hand out: workgroups beyond that leave before
+  // staging anything (a launch over a nearly empty queue took 50 us for its 4096 workgroups to stage their tables)
+  if (blockIdx.x != 0 && (unsigned long long)blockIdx.x * RT_SHADE_CHUNK >= n) return;
   uint32_t probes = 0, drops = 0, dead = 0;
   __shared__ uint32_t s_first, s_out_base;
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
