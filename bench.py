@@ -36,12 +36,12 @@ BOUNCE_BYTES = 390
 # correction; it is calibrated for 16-byte loads and these are 8- and 4-byte ones, so an upper bound; the algorithmic
 # reads are 52.3e9 B) + WRITE_SIZE 59.07e9 B (hit records 17.1e9 B, queue records of the new paths 41.2e9 B).
 TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 42.95e9 + 59.07e9) / 1.0699e9
-# The same for the shading kernel: FETCH_SIZE 136.1e9 B doubled + WRITE_SIZE 68.78e9 B (algorithmic: about 113e9 read,
+# The same for the shading kernel: FETCH_SIZE 135.8e9 B doubled + WRITE_SIZE 68.89e9 B (algorithmic: about 113e9 read,
 # 57.2e9 of survivor records and dead entries + up to 10.8e9 of pixel atomics written).  The reads exceed the algorithmic bytes because
 # the kernel shades each chunk of 4096 queue entries in sorted order: a 128-byte line of a queue array holds 16
 # entries that are shaded by different waves at different times, and the chunks in flight (416 KB each, two per CU)
 # outgrow the 4 MB L2 of an XCD, so lines come back from the Infinity Cache, which these counters count.
-SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 136.1e9 + 68.78e9) / 1.0699e9
+SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 135.8e9 + 68.89e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
 
 
