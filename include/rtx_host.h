@@ -118,6 +118,11 @@ rtx_status rtxh_camera_render_progressive(rtxh_session* s, rtx_context* ctx, rtx
                                           rtxh_progress_fn progress, void* user, const char* output_filename,
                                           uint8_t* rgb_out, int* rows_done_out);
 
+/* The identity of (scene, camera) a checkpoint stores: a hash over every table of the description with its count
+ * (geometry, transforms, media, materials, textures, texels, Perlin tables, lights) and the camera.  A checkpoint
+ * whose value differs is not resumed.  No counterpart in the reference. */
+uint64_t rtxh_checkpoint_fingerprint(const rtx_scene_desc* desc, const rtx_camera_desc* cam);
+
 /* RgbImage::save (camera.rs:322): 8-bit RGB PNG through zlib. */
 rtx_status rtxh_write_png(const char* path, const uint8_t* rgb, int width, int height);
 

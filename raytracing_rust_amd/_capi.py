@@ -167,6 +167,7 @@ SYMBOLS = {
     "rtxh_camera_render": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_char_p, C.POINTER(u8), PD]),
     "rtxh_camera_render_progressive": (C.c_int, [P, P, C.POINTER(CameraDesc), C.c_int, C.c_int, u64, C.c_int, C.c_char_p,
                                                  PROGRESS_FN, P, C.c_char_p, C.POINTER(u8), C.POINTER(C.c_int)]),
+    "rtxh_checkpoint_fingerprint": (u64, [C.POINTER(SceneDesc), C.POINTER(CameraDesc)]),
     "rtxh_write_png": (C.c_int, [C.c_char_p, C.POINTER(u8), C.c_int, C.c_int]),
 }
 

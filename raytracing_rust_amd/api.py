@@ -197,6 +197,17 @@ class ConstantMedium(Hittable):
     def new_color(cls, boundary, density, color): return cls(session().medium(boundary.h, density, session().solid(*color)))
 
 
+def _failure_message():
+    """rtxh_camera_render clears the messages of both layers when it starts, so whichever is set afterwards belongs to
+    the step that failed: the device layer's (the context's, or the context-less one of the camera checks), else the
+    session's (flattening)."""
+    for msg in (_capi.lib.rtx_last_error(context().handle), _capi.lib.rtx_last_error(None),
+                _capi.lib.rtxh_last_error(session().session)):
+        if msg:
+            return msg.decode()
+    return ""
+
+
 class Camera:
     """rendering/camera.rs:16-49; `render` is camera.rs:271-328 with the pixel loops on the GPU."""
 
@@ -235,8 +246,7 @@ class Camera:
                                           -1 if lights is None else lights.h, self.seed, fn,
                                           rgb.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(secs))
         if st != _capi.RTX_OK:
-            msg = _capi.lib.rtx_last_error(context().handle) or _capi.lib.rtxh_last_error(session().session)
-            raise _r.RtxError(st, msg.decode() if msg else "")
+            raise _r.RtxError(st, _failure_message())
         self.last_render_seconds = secs.value
         return rgb
 
@@ -254,6 +264,5 @@ class Camera:
             int(rows_per_batch), str(checkpoint).encode() if checkpoint else None, cb, None, fn,
             rgb.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(done))
         if st != _capi.RTX_OK:
-            msg = _capi.lib.rtx_last_error(context().handle) or _capi.lib.rtxh_last_error(session().session)
-            raise _r.RtxError(st, msg.decode() if msg else "")
+            raise _r.RtxError(st, _failure_message())
         return rgb, done.value

@@ -626,6 +626,7 @@ int rtxh_bounding_box(rtxh_session* s, int object, double* out) {
 
 rtx_status rtxh_flatten(rtxh_session* s, int world, int lights, rtx_scene_desc* out) {
   if (!s || !out) return RTX_ERR_INVALID;
+  s->error.clear();   // the message, if any, is this call's
   if (!s->ok_obj(world) || (lights >= 0 && !s->ok_obj(lights))) { s->error = "flatten: bad handle"; return RTX_ERR_INVALID; }
   s->nodes.clear(); s->boxes.clear(); s->xforms.clear(); s->ops.clear(); s->media.clear(); s->lights.clear();
   rtx_xform root;

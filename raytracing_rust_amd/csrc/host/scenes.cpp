@@ -13,6 +13,7 @@
 
 #include "../../../include/rtx_host.h"
 #include "host_internal.h"
+#include "../device_internal.h"
 
 using namespace rtxh;
 
@@ -204,7 +205,9 @@ int rtxh_scene_stress(rtxh_session* s, int n_prims, uint64_t seed, int width, in
 
 // Camera::initialize, camera.rs:89-129.
 rtx_status rtx_camera_initialize(rtx_camera_desc* c) {
-  if (!c || c->image_width < 1 || !(c->aspect_ratio > 0.0) || c->samples_per_pixel < 1) return RTX_ERR_INVALID;
+  if (!c) return rtx_internal_fail(nullptr, RTX_ERR_INVALID, "rtx_camera_initialize: null camera");
+  if (c->image_width < 1 || !(c->aspect_ratio > 0.0) || c->samples_per_pixel < 1)
+    return rtx_internal_fail(nullptr, RTX_ERR_INVALID, "rtx_camera_initialize: image_width and samples_per_pixel must be at least 1 and aspect_ratio positive");
   c->image_height = (int32_t)((double)c->image_width / c->aspect_ratio);
   if (c->image_height < 1) c->image_height = 1;
   c->sqrt_spp = (int32_t)sqrt((double)c->samples_per_pixel);
@@ -281,6 +284,7 @@ rtx_status rtxh_write_png(const char* path, const uint8_t* rgb, int width, int h
 rtx_status rtxh_camera_render(rtxh_session* s, rtx_context* ctx, rtx_camera_desc* cam, int world, int lights,
                               uint64_t seed, const char* output_filename, uint8_t* rgb_out, double* seconds_out) {
   if (!s || !ctx || !cam) return RTX_ERR_INVALID;
+  rtx_internal_fail(ctx, RTX_OK, "");   // a message left by an earlier call must not be taken for this call's
   rtx_status st = rtx_camera_initialize(cam);
   if (st != RTX_OK) return st;
   rtx_scene_desc desc;
@@ -316,7 +320,8 @@ rtx_status rtxh_camera_render(rtxh_session* s, rtx_context* ctx, rtx_camera_desc
 // ---- progressive rendering with checkpoints -------------------------------------------------------------------
 namespace {
 struct CkptHeader {
-  char magic[8];                       // "RTXCKPT1"
+  char magic[8];                       // "RTXCKPT2"
+  uint32_t header_bytes, _pad;         // sizeof(CkptHeader) of the build that wrote the file
   int32_t width, height, sqrt_spp, samples_per_pixel, max_depth, next_row;
   uint64_t seed, fingerprint;
 };
@@ -325,15 +330,29 @@ uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
   for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
   return h;
 }
-// A cheap identity of scene + camera: a checkpoint of another render must not be resumed.
+// A cheap identity of scene + camera: a checkpoint of another render must not be resumed.  Every table of the
+// description goes in, with its count: a changed fog density, transform, light list or texel must not match.
 uint64_t fingerprint(const rtx_scene_desc& d, const rtx_camera_desc& c) {
   uint64_t h = 1469598103934665603ull;
-  h = fnv1a(h, d.nodes, sizeof(rtx_node) * d.n_nodes);
-  h = fnv1a(h, d.boxes, sizeof(rtx_aabb) * d.n_boxes);
-  h = fnv1a(h, d.spheres, sizeof(rtx_sphere) * d.n_spheres);
-  h = fnv1a(h, d.quads, sizeof(rtx_quad) * d.n_quads);
-  h = fnv1a(h, d.materials, sizeof(rtx_material) * d.n_materials);
-  h = fnv1a(h, d.textures, sizeof(rtx_texture) * d.n_textures);
+  auto table = [&](const void* p, uint64_t count, size_t elem) {
+    h = fnv1a(h, &count, sizeof(count));
+    if (count) h = fnv1a(h, p, (size_t)count * elem);
+  };
+  table(d.nodes, d.n_nodes, sizeof(rtx_node));
+  table(d.boxes, d.n_boxes, sizeof(rtx_aabb));
+  table(d.spheres, d.n_spheres, sizeof(rtx_sphere));
+  table(d.quads, d.n_quads, sizeof(rtx_quad));
+  table(d.xforms, d.n_xforms, sizeof(rtx_xform));
+  table(d.xform_ops, d.n_xform_ops, sizeof(rtx_xform_op));
+  table(d.media, d.n_media, sizeof(rtx_medium));
+  table(d.materials, d.n_materials, sizeof(rtx_material));
+  table(d.textures, d.n_textures, sizeof(rtx_texture));
+  table(d.images, d.n_images, sizeof(rtx_image));
+  table(d.texels, d.n_texel_bytes, 1);
+  table(d.perlins, d.n_perlins, sizeof(rtx_perlin));
+  table(d.lights, d.n_lights, sizeof(rtx_light));
+  const uint32_t tail[3] = {d.world_begin, d.world_end, d.has_lights};
+  h = fnv1a(h, tail, sizeof(tail));
   h = fnv1a(h, &c, sizeof(c));
   return h;
 }
@@ -350,7 +369,8 @@ bool save_checkpoint(const char* path, const CkptHeader& hd, const std::vector<d
 bool load_checkpoint(const char* path, const CkptHeader& want, CkptHeader& got, std::vector<double>& accum) {
   FILE* f = fopen(path, "rb");
   if (!f) return false;
-  bool ok = fread(&got, sizeof(got), 1, f) == 1 && memcmp(got.magic, want.magic, 8) == 0 && got.width == want.width &&
+  bool ok = fread(&got, sizeof(got), 1, f) == 1 && memcmp(got.magic, want.magic, 8) == 0 && got.header_bytes == want.header_bytes &&
+            got.width == want.width &&
             got.height == want.height && got.sqrt_spp == want.sqrt_spp && got.samples_per_pixel == want.samples_per_pixel &&
             got.max_depth == want.max_depth && got.seed == want.seed && got.fingerprint == want.fingerprint &&
             got.next_row >= 0 && got.next_row <= want.sqrt_spp;
@@ -362,11 +382,17 @@ bool load_checkpoint(const char* path, const CkptHeader& want, CkptHeader& got, 
 }
 }  // namespace
 
+uint64_t rtxh_checkpoint_fingerprint(const rtx_scene_desc* desc, const rtx_camera_desc* cam) {
+  if (!desc || !cam) return 0;
+  return fingerprint(*desc, *cam);
+}
+
 rtx_status rtxh_camera_render_progressive(rtxh_session* s, rtx_context* ctx, rtx_camera_desc* cam, int world, int lights,
                                           uint64_t seed, int rows_per_batch, const char* checkpoint_path,
                                           rtxh_progress_fn progress, void* user, const char* output_filename,
                                           uint8_t* rgb_out, int* rows_done_out) {
   if (!s || !ctx || !cam || rows_per_batch < 1) return RTX_ERR_INVALID;
+  rtx_internal_fail(ctx, RTX_OK, "");
   rtx_status st = rtx_camera_initialize(cam);
   if (st != RTX_OK) return st;
   rtx_scene_desc desc;
@@ -379,7 +405,8 @@ rtx_status rtxh_camera_render_progressive(rtxh_session* s, rtx_context* ctx, rtx
   std::vector<double> accum(npix * 3, 0.0);
   CkptHeader hd;
   memset(&hd, 0, sizeof(hd));
-  memcpy(hd.magic, "RTXCKPT1", 8);
+  memcpy(hd.magic, "RTXCKPT2", 8);
+  hd.header_bytes = (uint32_t)sizeof(CkptHeader);
   hd.width = cam->image_width; hd.height = cam->image_height; hd.sqrt_spp = cam->sqrt_spp;
   hd.samples_per_pixel = cam->samples_per_pixel; hd.max_depth = cam->max_depth; hd.seed = seed;
   hd.fingerprint = fingerprint(desc, *cam);

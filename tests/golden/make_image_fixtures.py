@@ -1,7 +1,11 @@
-"""Block means of the reference's own output images (images/cornell_box.png, images/output_cornell_smoke.png,
-images/quick_test.png): the only reference-produced data for this path.  Each 8-bit image is averaged over a
-30 x 30 grid of blocks (20 x 20 pixels at 600 x 600) per channel and stored as float32; the tests render the same
-scene, average the same way and compare loosely (the reference's sample count and random streams are unknown).
+"""Block means of the reference's own output images: the only reference-produced data for this path.
+reference_image_blocks.npz: images/cornell_box.png, images/output_cornell_smoke.png (and images/quick_test.png cropped)
+averaged over a 30 x 30 grid of blocks (20 x 20 pixels at 600 x 600) per channel, float32.
+reference_image_blocks10.npz: the final scene's images - images/quick_test.png (400 x 400, the `quick` entry point),
+images/output_final_scene_800x800_5000spp.png and images/output_final_scene_800x800_10000spp.png - over a 10 x 10 grid:
+that scene's boxes, sphere cluster and marble are random per run (final_scene.rs:58,155-159), so only its large-scale
+layout and brightness are comparable.  The tests render the same scene, average the same way and compare loosely
+(the reference's sample count and random streams are unknown).
 
     python tests/golden/make_image_fixtures.py /root/reference
 """
@@ -34,5 +38,20 @@ def main():
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_image_blocks.npz"), **out)
 
 
+FINAL_IMAGES = {"quick": "quick_test.png", "final_5000spp": "output_final_scene_800x800_5000spp.png",
+                "final_10000spp": "output_final_scene_800x800_10000spp.png"}
+
+
+def main10():
+    ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+    out = {}
+    for name, fn in FINAL_IMAGES.items():
+        img = np.asarray(Image.open(os.path.join(ref, "images", fn)).convert("RGB"))
+        out[name] = block_means(img, 10)
+        print(name, img.shape, out[name].mean(axis=(0, 1)))
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_image_blocks10.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    main10()

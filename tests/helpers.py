@@ -165,3 +165,37 @@ def build_both(build_fn):
     go, gp = oracle_graph(), rt.Graph()
     ro, rp = build_fn(go), build_fn(gp)
     return go, ro, gp, rp
+
+
+def camera_rays(cam, sample, seed):
+    """The device's camera ray of every pixel for one stratified sample index (Camera::get_ray with the path RNG's
+    addressing; only + - x / on doubles, so the host build and the GPU make the same bits).  (H*W, 7)."""
+    lib = hostsim_lib()
+    out = np.empty((cam.image_height * cam.image_width, 7))
+    buf = (C.c_double * 7)()
+    k = 0
+    for j in range(cam.image_height):
+        for i in range(cam.image_width):
+            lib.sim_camera_ray(C.byref(cam), i, j, sample, seed, buf)
+            out[k] = buf[:]
+            k += 1
+    return out
+
+
+def oracle_first_bounce_emission(g, world, texs, cam, sample, seed):
+    """What a path of depth 1 returns in the oracle for the device's camera rays of one sample index, when every
+    primitive of `world` is a DiffuseLight whose texture is texs[prim_id]: the texture value at the oracle's own hit
+    record (u, v, p), or the background for a miss (camera.rs:179-190).  (H, W, 3)."""
+    rays = camera_rays(cam, sample, seed)
+    hit = oracle_first_hit(g, world, rays)
+    out = np.empty((len(rays), 3))
+    out[:] = np.array(cam.background[:])
+    for prim, tex in enumerate(texs):
+        sel = np.nonzero(hit["prim_id"] == prim)[0]
+        if sel.size == 0:
+            continue
+        uvp = np.ascontiguousarray(np.concatenate([hit["uv"][sel], hit["p"][sel]], axis=1))
+        val = np.empty((sel.size, 3))
+        assert oracle_lib().orc_tex_value(g.session, tex, dptr(uvp), sel.size, dptr(val)) == 0
+        out[sel] = val
+    return out.reshape(cam.image_height, cam.image_width, 3), hit

@@ -62,6 +62,23 @@ def test_textures_bit_exact_vs_oracle():
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+def test_texture_probe_first_bounce_bit_exact_vs_oracle():
+    """Every texture kind as the emission of a light, max_depth 1: a pixel holds the texture value at its camera ray's
+    hit.  The host build of the device core (same libm as the oracle) must reproduce the oracle's hit record fed to
+    the oracle's Texture::value exactly, spheres' (u, v) included; the GPU tier runs the same probe on the device."""
+    import recipes
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, camkw, tex_o = recipes.texture_probe(go)
+    wp, _, _ = recipes.texture_probe(gp)
+    cam = rt.initialize_camera(rt.camera_desc(**camkw))
+    desc = rt.flatten(gp, wp, None)
+    for s in (0, 3):
+        want, hit = H.oracle_first_bounce_emission(go, wo, tex_o, cam, s, 4242)
+        got, _ = H.hostsim_render(desc, cam, rt.render_opts(cam, sample_begin=s, sample_end=s + 1, seed=4242))
+        assert (got == want).all()
+        assert all((hit["prim_id"] == k).sum() > 500 for k in range(len(tex_o)))
+
+
 @pytest.mark.parametrize("name", ["cornell", "final"])
 def test_light_pdf_bit_exact_vs_oracle(name):
     """lights.pdf_value(origin, dir) (hittable_list.rs:78-88 over quad.rs:102-113 / sphere.rs:125-137)."""

@@ -59,21 +59,93 @@ def test_first_hit_aov_bit_exact_recipes(gpu_ctx, recipe):
     scene.close()
 
 
-def test_gpu_matches_host_build_of_same_code(gpu_ctx):
+@pytest.mark.parametrize("name,width,spp,depth", [("cornell", 48, 16, 12), ("smoke", 96, 16, 20), ("quick", 96, 16, 20),
+                                                  ("final", 96, 16, 75)])
+def test_gpu_matches_host_build_of_same_code(gpu_ctx, name, width, spp, depth):
     """Same counter-based RNG addressing on both sides: the GPU render and the host build of the device core trace
-    the same paths; only libm-vs-OCML transcendentals differ, so sums agree to a tight tolerance."""
+    the same paths; only libm-vs-OCML transcendentals differ, so sums agree to a tight tolerance (stated here: the
+    segment counts within 0.2 %, at least 99.5 % of the channels within 1e-6 relative).  The host build is bit-exact
+    against the oracle on textures, light pdfs and first hits (CPU tier), so this pins, on the GPU and through the
+    default wavefront pipeline, everything the final scene has and the Cornell box lacks: both BVHs with their head
+    and deferred sections, Perlin noise (procedural/noise.rs:35-127), the image lookup (image.rs:58-88), metal
+    (metal.rs:24-38), the moving sphere and both constant media (constant_medium.rs:42-90).  Beyond the block means of
+    the reference's PNGs the oracle itself is parity unpinned (no toolchain, no vectors in the reference)."""
     gp = rt.Graph()
-    wp, lp, cam = scenes.build("cornell", gp, width=48, spp=16, depth=12)
+    wp, lp, cam = scenes.build(name, gp, width=width, spp=spp, depth=depth)
     desc = rt.flatten(gp, wp, lp)
     scene = rt.Scene(gpu_ctx, desc)
     gpu_ctx.reset_stats()
     a = scene.render(cam, rt.render_opts(cam, seed=11))
     st = gpu_ctx.stats()
     b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, seed=11))
-    assert st["paths"] == cb["paths"] == 48 * 48 * 16
+    assert st["paths"] == cb["paths"] == width * cam.image_height * cam.sqrt_spp ** 2
     assert abs(st["segments"] - cb["segments"]) <= 0.002 * cb["segments"]
     close = np.isclose(a, b, rtol=1e-6, atol=1e-9)
-    assert close.mean() > 0.995, f"only {close.mean():.4f} of the channels agree"
+    assert close.mean() > 0.995, f"{name}: only {close.mean():.4f} of the channels agree"
+    assert b.sum() > 0 and abs(a.sum() - b.sum()) < 2e-3 * b.sum()
+    scene.close()
+
+
+def test_texture_probe_first_bounce_matches_oracle(gpu_ctx):
+    """Checker (checker.rs:41-56), a checker of a checker with noise and image children, marble noise at two scales
+    (texture/noise.rs:29-35), the earth image, a missing image (cyan) - each as the emission of a light, rendered with
+    max_depth 1 so that every pixel holds exactly the texture value at its camera ray's hit.  Expected values: the
+    oracle's hit record (u, v, p) on the same rays fed to the oracle's Texture::value.  Tolerance 1e-12 absolute on
+    the quads (their (u, v) are rational in the ray: no transcendental before the lookup; sin in the noise texture
+    differs by an ulp between libm and the device); on the two spheres (u, v) come from acos / atan2, so a lookup
+    next to a texel or checker boundary may land on the other side: at least 99.5 % of their pixels must agree."""
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, camkw, tex_o = recipes.texture_probe(go)
+    wp, _, _ = recipes.texture_probe(gp)
+    cam = rt.initialize_camera(rt.camera_desc(**camkw))
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, None)
+    seen = np.zeros(len(tex_o), dtype=np.int64)
+    for s in range(cam.sqrt_spp ** 2):
+        want, hit = H.oracle_first_bounce_emission(go, wo, tex_o, cam, s, 4242)
+        got = scene.render(cam, rt.render_opts(cam, sample_begin=s, sample_end=s + 1, seed=4242))
+        err = np.abs(got - want).max(axis=2).ravel()
+        prim = hit["prim_id"]
+        flat = (prim < 6) | (prim == 0xFFFFFFFF)           # quads, and misses (background)
+        assert err[flat].max() <= 1e-12, f"sample {s}: quad pixels off by {err[flat].max()}"
+        for k in (6, 7):
+            sel = prim == k
+            assert (err[sel] <= 1e-12).mean() >= 0.995, f"sample {s}: sphere {k}: {(err[sel] > 1e-12).sum()} of {sel.sum()} pixels differ"
+        seen += np.bincount(prim[prim < len(tex_o)], minlength=len(tex_o))
+    assert (seen > 2000).all(), seen                       # every texture was looked at
+    scene.close()
+
+
+def test_converged_image_full_size_quick(gpu_ctx):
+    """The `quick` entry point at its full size (main.rs:31-39: final scene, 400 x 400, 100 spp, depth 20) against the
+    oracle at equal spp with independent random streams.  Stated tolerances, on radiance clamped to the display range
+    [0, 1] (color.rs:44-49 clamps the output there; the light's 7.0 would otherwise dominate every norm):
+    per-pixel relative RMSE (RMSE / mean) below 0.40 and within 6 % of the same distance between two GPU renders with
+    different seeds (two independent estimates of one image are exactly that far apart); the same on 8 x 8 block
+    means within 15 % of the GPU-to-GPU distance (a systematic 2 % error of the block means would add 10 %); mean
+    radiance within 0.5 %."""
+    go, wo, lo, gp, wp, lp, cam = _pair("quick")
+    assert (cam.image_width, cam.image_height, cam.sqrt_spp, cam.max_depth) == (400, 400, 10, 20)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    n = cam.sqrt_spp ** 2
+    a1 = scene.render(cam, rt.render_opts(cam, seed=301)) / n
+    a2 = scene.render(cam, rt.render_opts(cam, seed=302)) / n
+    b, _ = H.oracle_render(go, wo, lo, cam, seed=303)
+    b /= n
+    assert np.isfinite(a1).all() and np.isfinite(b).all()
+
+    def rrmse(x, y, k):
+        x, y = np.minimum(x, 1.0), np.minimum(y, 1.0)
+        if k > 1:
+            x, y = (z.reshape(400 // k, k, 400 // k, k, 3).mean(axis=(1, 3)) for z in (x, y))
+        return np.sqrt(((x - y) ** 2).mean()) / y.mean()
+
+    noise1, noise8 = rrmse(a1, a2, 1), rrmse(a1, a2, 8)
+    for a in (a1, a2):
+        d1, d8 = rrmse(a, b, 1), rrmse(a, b, 8)
+        assert d1 < 0.40 and abs(d1 / noise1 - 1.0) < 0.06, f"per pixel: GPU-vs-oracle {d1:.4f}, GPU-vs-GPU {noise1:.4f}"
+        assert d8 < 1.15 * noise8, f"8x8 blocks: GPU-vs-oracle {d8:.4f}, GPU-vs-GPU {noise8:.4f}"
+    rel = abs(0.5 * (a1 + a2).mean() - b.mean()) / b.mean()
+    assert rel < 0.005, f"mean radiance differs by {rel:.4f}"
     scene.close()
 
 
