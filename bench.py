@@ -5,13 +5,23 @@
 
 A step is one pass of the hot path over one batch: ONE render call of the whole configuration the metric is quoted on,
 every pixel of the 800x800 frame traced for all 70 x 70 = 4900 stratified sample indices (3.136 G camera paths;
-`--rows R` renders R of the 70 rows per step instead).  Every (rank, step) gets its own path seed (weak scaling:
-per-GPU work is fixed), all ranks' accumulators are summed on rank 0 with one reduce (RCCL) inside the timed region,
-and rank 0 copies the sum to the host.  Prints ONE JSON line on rank 0.
+`--rows R` renders R of the 70 rows per step instead).
+
+With N > 1 the command starts its own ranks (one process per GPU through torch.distributed.run; the parent process
+never touches a GPU) unless it already runs under a launcher (WORLD_SIZE set).  Two modes are timed, each over K
+steps between barriers, maximum over ranks:
+  weak    (the headline `value`): every (rank, step) renders a whole frame with its own path seed; the ranks'
+          accumulators are summed on rank 0 with one reduce (RCCL) and copied to the host inside the timed region.
+  strong  (`strong_scaling`): ONE frame per step, its 70 rows of the stratification split between the ranks, reduce and
+          copy to the host after every frame: the 800x800x5000spp image on N GPUs.
+Rank 0 then measures the roofline block (a short single-pipeline render, so that kernels run one at a time and their
+durations are exclusive) and, at N = 1, the CPU baseline.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,43 +31,161 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 WIDTH, SPP, DEPTH = 800, 5000, 75          # src/main.rs:22-29
-# Algorithmic bytes per ray segment.  World-program traversal kernel (k_wf_traverse<true,false,1,true>, the kernel with the
-# largest share of GPU time): reads the ray (origin, direction, time: 7 doubles), the path's RNG address because the
-# scene has media (pixel, sample, bounce: 3 u32) and the hit the head-section launch left (t f64, kind_idx u32, ctx
-# u32); writes the hit: 56 + 12 + 16 + 16 = 100 B (84 B when the head section is not walked separately).  A whole
-# bounce adds the head-section launch (ray 56 in, hit 16 out), the deferred-section launch (4 + 56 + 16 in, 16 out
-# for one ray in nine), the shading kernel's reads (16 B for its sort, then ray 56 + throughput 24 + ids 12 + hit 16 =
-# 108 B unless the roulette ended the path) and its survivor record (80 + 12 = 92 B) or pixel atomics (24 B): about 390 B.
-TRAVERSE_BYTES = 100
-TRAVERSE_BYTES_UNSPLIT = 84
-BOUNCE_BYTES = 390
-# HBM-side traffic of that kernel per segment, from rocprofv3 PMC passes over this command with --rows 10 --steps 1
-# --warmup 0 (1.0699e9 segments; profiles/r1_pmc_summary.txt): FETCH_SIZE 42.95e9 B doubled (the gfx950 half-count
-# correction; it is calibrated for 16-byte loads and these are 8- and 4-byte ones, so an upper bound; the algorithmic
-# reads are 52.3e9 B) + WRITE_SIZE 59.07e9 B (hit records 17.1e9 B, queue records of the new paths 41.2e9 B).
-TRAVERSE_PMC_TRAFFIC_PER_SEGMENT = (2 * 42.95e9 + 59.07e9) / 1.0699e9
-# The same for the shading kernel: FETCH_SIZE 135.8e9 B doubled + WRITE_SIZE 68.89e9 B (algorithmic: about 113e9 read,
-# 57.2e9 of survivor records and dead entries + up to 10.8e9 of pixel atomics written).  The reads exceed the algorithmic bytes because
-# the kernel shades each chunk of 4096 queue entries in sorted order: a 128-byte line of a queue array holds 16
-# entries that are shaded by different waves at different times, and the chunks in flight (416 KB each, two per CU)
-# outgrow the 4 MB L2 of an XCD, so lines come back from the Infinity Cache, which these counters count.
-SHADE_PMC_TRAFFIC_PER_SEGMENT = (2 * 135.8e9 + 68.89e9) / 1.0699e9
 HBM_PEAK_GBS = 8000.0
+# Algorithmic bytes per ray segment (one world.hit of ray_color, camera.rs:179).
+#   a-priori figures for an f64 wavefront layout: traversal kernel 80 B (ray origin, direction, time, tmax = 64 in;
+#   hit t, primitive, flags = 16 out); whole bounce 328 B (traversal 80 + shading reads them back 80 + path state 40 in,
+#   next ray 64 + state 40 out, 24 of radiance).
+#   what this build's kernels move: the world-program traversal reads ray 56 + RNG address 12 (the scene has media) +
+#   the hit the head-section launch left 16 and writes the hit 16 = 100 B for a surviving path; for a NEW camera path
+#   it reads nothing and writes the queue record 92 + hit 16 = 108 B.  Head-section stream: ray 56 in, hit 16 out.
+#   Deferred-section stream: index 4 + ray 56 + hit 16 in, hit 16 out, per ray that entered the section.  Shading: 16 B
+#   per entry for the sort, 108 B in for an entry the roulette did not end, then a survivor record 92 B or 24 B of
+#   pixel atomics.  Whole bounce: about 390 B.
+SURVEY_TRAVERSE_BYTES, SURVEY_BOUNCE_BYTES = 80, 328
+OWN_TRAVERSE_BYTES, OWN_NEW_PATH_BYTES, OWN_BOUNCE_BYTES = 100, 108, 390
+# Counter-derived constants of the profiled build (rocprofv3 --pmc passes over `RTX_WF_LANES=1 python bench.py --rows 10
+# --steps 1 --warmup 0 --no-cpu-baseline`; profiles/README.md names the commit).  Per ray segment of the whole
+# pipeline: VALU wave instructions, and per kernel the HBM-side bytes (FETCH_SIZE doubled as the gfx950 correction for
+# wide loads prescribes - an upper bound here, the loads are 4 and 8 bytes per lane - plus WRITE_SIZE) and the lanes
+# active per VALU instruction.
+PMC = {
+    "profile": "profiles/r1_pmc_summary.txt",
+    "valu_wave_instructions_per_segment": 73.0,
+    "traffic_bytes_per_segment": {"k_wf_traverse": (2 * 42.95e9 + 59.07e9) / 1.0699e9, "k_wf_shade": (2 * 135.8e9 + 68.89e9) / 1.0699e9},
+    "lanes_active": {"k_wf_traverse": 58, "k_wf_stream_head": 42, "k_wf_stream_deferred": 36, "k_wf_shade": 42},
+}
+SIMDS, CLOCK_GHZ, F64_CYCLES_PER_WAVE_INSTRUCTION = 256 * 4, 2.4, 4   # vector f64: 16 lanes per clock per SIMD
 
 
-def cpu_baseline(threads, rows=1, samples=8):
-    """The oracle (a C++ restatement of the reference, test infrastructure) on the host cores, bounded sample of the
-    same workload: the full 800x800 frame, `samples` sample indices of the 4900, depth 75."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(samples=8):
+    """The oracle (a C++ restatement of the reference, test infrastructure) on the host cores this job may use, on a
+    bounded sample of the same workload: the full 800x800 frame, `samples` sample indices of the 4900, depth 75."""
     import raytracing_rust_amd as rt
     import helpers as H
+    nproc = os.cpu_count() or 1
+    granted = nproc
+    try:   # a GPU box shows the whole machine's CPUs; the job's share is what its launcher exports
+        granted = min(nproc, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        granted = max(1, min(granted, int(os.environ["OMP_NUM_THREADS"])))
     g = H.oracle_graph()
     w, l, cam = rt.scenes.build("final", g, width=WIDTH, spp=SPP, depth=DEPTH, prefix="orc_", lib=H.oracle_lib())
     t0 = time.perf_counter()
-    _, cnt = H.oracle_render(g, w, l, cam, sample_begin=0, sample_end=samples, threads=threads)
+    _, cnt = H.oracle_render(g, w, l, cam, sample_begin=0, sample_end=samples, threads=granted)
     dt = time.perf_counter() - t0
-    return {"value": cnt["paths"] / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    return {"value": cnt["paths"] / dt / 1e6, "unit": "Msamples/s", "cores": granted, "kind": "port",
             "sample": f"final scene 800x800, sample indices [0,{samples}) of 4900, depth 75: {cnt['paths']} paths in {dt:.1f} s",
+            "nproc": nproc, "cpu_model": cpu_model(),
+            "cores_note": "every core this job may use (affinity mask, capped by the launcher's OMP_NUM_THREADS)",
             "Msegments_per_s": cnt["segments"] / dt / 1e6}
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a child process tree and pass its output and exit code on.
+    This process makes no GPU call before or after."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, torch):
+    """Exclusive kernel durations: `rows` rows of the stratification through ONE pipeline, so that no two kernels
+    share the GPU.  World-program traversal and shading are timed on the device (wall clock of the first block in and
+    the last block out of every launch), the two section streams with HIP events on the stream they are launched on."""
+    prev = os.environ.get("RTX_WF_LANES")
+    os.environ["RTX_WF_LANES"] = "1"
+    try:
+        torch.cuda.synchronize()
+        ctx.reset_stats()
+        accum.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scene.render_device(cam, rt.render_opts(cam, sample_begin=0, sample_end=rows * cam.sqrt_spp, seed=rt.scenes.PATH_SEED + 99), accum, stream)
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        st = ctx.stats()
+    finally:
+        if prev is None:
+            del os.environ["RTX_WF_LANES"]
+        else:
+            os.environ["RTX_WF_LANES"] = prev
+    seg, paths, it = float(st["segments"]), float(st["paths"]), max(1, st["iterations"])
+    if st["traverse_launches"] == 0:   # the fused pipeline was forced
+        ms = st["render_ms"]
+        ach = seg * SURVEY_BOUNCE_BYTES / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_render_fused", "kernel_ms": ms / max(1, st["launches"]), "algorithmic_bytes_per_segment": SURVEY_BOUNCE_BYTES}
+    new_frac = paths / seg
+    own_trav = OWN_TRAVERSE_BYTES * (1.0 - new_frac) + OWN_NEW_PATH_BYTES * new_frac
+    p_drop = st["roulette_drops"] / seg
+    p_survive = 1.0 - paths / seg
+    own_shade = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
+    # deferred rays are not counted by the library; one ray in nine enters the section in this scene (profiles/README.md)
+    kernels = [
+        ("k_wf_traverse<true,false,1,true>", "world program + camera rays", st["traverse_ms"], SURVEY_TRAVERSE_BYTES, own_trav, "k_wf_traverse"),
+        ("k_wf_shade", "shading + compaction", st["shade_ms"], SURVEY_BOUNCE_BYTES - SURVEY_TRAVERSE_BYTES, own_shade, "k_wf_shade"),
+        ("k_wf_stream<true,false,0>", "head section (ground BVH), survivors", st["head_ms"], SURVEY_TRAVERSE_BYTES, 72.0 * (1.0 - new_frac), "k_wf_stream_head"),
+        ("k_wf_stream<true,true,1>", "deferred section (sphere cluster)", st["tail_ms"], SURVEY_TRAVERSE_BYTES / 9.0, 92.0 / 9.0, "k_wf_stream_deferred"),
+    ]
+    total_ms = sum(k[2] for k in kernels)
+    out = []
+    for name, what, ms, survey_b, own_b, key in kernels:
+        if ms <= 0.0:
+            continue
+        ach = seg * survey_b / (ms * 1e-3) / 1e9
+        traffic = PMC["traffic_bytes_per_segment"].get(key)
+        out.append({"kernel": name, "what": what, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_segment": survey_b, "algorithmic_bytes_per_launch": survey_b * seg / it,
+                    "achieved_own_bytes": seg * own_b / (ms * 1e-3) / 1e9, "frac_own_bytes": seg * own_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "own_bytes_per_segment": own_b,
+                    "kernel_ms": ms / it, "launches": it, "segments_per_launch": seg / it, "gpu_ms": ms,
+                    "share_of_kernel_time": ms / total_ms,
+                    "traffic": None if traffic is None else traffic * seg / it,
+                    "lanes_active_per_valu_instruction": PMC["lanes_active"].get(key)})
+    out.sort(key=lambda r: -r["gpu_ms"])
+    rl = dict(out[0])
+    seg_s = seg / (wall_ms * 1e-3)
+    rl.update({
+        "kernel_ms_source": f"single-pipeline pass (RTX_WF_LANES=1) over {rows} of the 70 rows: kernels run one at a time, so durations "
+                            "are exclusive; device wall clock per launch for traversal and shading, HIP events on the launch "
+                            "stream for the section streams; averages are over every launch, empty ones included, as a profiler counts",
+        "traffic_source": f"rocprofv3 --pmc FETCH_SIZE (doubled) + WRITE_SIZE passes, {PMC['profile']}",
+        "pass": {"rows": rows, "wall_ms": wall_ms, "sum_kernel_ms": total_ms, "segments": seg, "paths": paths,
+                 "Msegments_per_s": seg_s / 1e6, "Msamples_per_s": paths / (wall_ms * 1e-3) / 1e6},
+        "other_kernels": out[1:],
+        "whole_bounce": {"note": "all kernels of a bounce over the WALL time of the timed region (all pipelines)",
+                         "algorithmic_bytes_per_segment": SURVEY_BOUNCE_BYTES,
+                         "achieved": wall_seg_per_s * SURVEY_BOUNCE_BYTES / 1e9, "frac": wall_seg_per_s * SURVEY_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,
+                         "own_bytes_per_segment": OWN_BOUNCE_BYTES,
+                         "achieved_own_bytes": wall_seg_per_s * OWN_BOUNCE_BYTES / 1e9, "frac_own_bytes": wall_seg_per_s * OWN_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,
+                         "unit": "GB/s"},
+        # what actually bounds these kernels: f64 VALU issue with partly filled waves
+        "valu": {"bound": "f64 VALU issue", "wave_instructions_per_segment": PMC["valu_wave_instructions_per_segment"],
+                 "cycles_per_wave_instruction": F64_CYCLES_PER_WAVE_INSTRUCTION, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                 "issue_utilisation": wall_seg_per_s * PMC["valu_wave_instructions_per_segment"] * F64_CYCLES_PER_WAVE_INSTRUCTION / (SIMDS * CLOCK_GHZ * 1e9),
+                 "lanes_active_of_64": PMC["lanes_active"], "source": PMC["profile"],
+                 "note": "share of the issue slots of 1024 SIMDs at 2.4 GHz over the timed region, every VALU instruction "
+                         "priced as vector f64 (4 cycles per wave); the count per segment is a counter measurement of the profiled build"},
+        "note": "f64 VALU- and latency-bound code: the scene is LDS/L2-resident, the HBM streams of rays, hits and path state are "
+                "the only bytes it must move"})
+    return rl
 
 
 def main():
@@ -67,11 +195,16 @@ def main():
     ap.add_argument("--rows", type=int, default=70, help="rows of the 70x70 stratification per step (a divisor of 70)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both", help="modes to time when --gpus > 1")
+    ap.add_argument("--roofline-rows", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=256)
     args = ap.parse_args()
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    import torch   # before the package: in a process that holds both, PyTorch's HIP runtime has to be loaded first
     import raytracing_rust_amd as rt
     from raytracing_rust_amd import sharding
 
@@ -79,7 +212,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
     # RTX_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo collectives on host copies, to rehearse the multi-rank
@@ -104,12 +237,7 @@ def main():
     npix = cam.image_width * cam.image_height
     accum = torch.zeros(npix * 3, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-
-    def step(k):
-        # batch unique per (rank, step); past the 70 rows of the stratification, go on with another seed
-        b, e, seed = sharding.sample_batch(rank, k, args.steps + args.warmup, rows, rt.scenes.PATH_SEED, args.rows)
-        opts = rt.render_opts(cam, sample_begin=b, sample_end=e, seed=seed, pipeline=args.pipeline)
-        scene.render_device(cam, opts, accum, stream)
+    host = None
 
     def fence():
         torch.cuda.synchronize()
@@ -117,93 +245,95 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    ctx.reset_stats()
-    accum.zero_()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    if rehearsal and dist is not None:
-        host = accum.cpu()
-        sharding.reduce_sum(host, dist, dst=0)
-    else:
+    def reduce_to_host():
+        if rehearsal and dist is not None:
+            h = accum.cpu()
+            sharding.reduce_sum(h, dist, dst=0)
+            return h
         sharding.reduce_sum(accum, dist, dst=0)
-        if rank == 0:
-            host = accum.cpu()
-    fence()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()
-    if dist is not None:
-        t = torch.tensor([dt, float(st["segments"]), float(st["paths"])], dtype=torch.float64, device=coll)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, segments, paths = float(tmax[0]), float(t[1]), float(t[2])
-    else:
-        segments, paths = float(st["segments"]), float(st["paths"])
+        return accum.cpu() if rank == 0 else None
+
+    def weak_step(k):
+        # batch unique per (rank, step); past the 70 rows of the stratification, go on with another seed
+        b, e, seed = sharding.sample_batch(rank, k, args.steps + args.warmup, rows, rt.scenes.PATH_SEED, args.rows)
+        scene.render_device(cam, rt.render_opts(cam, sample_begin=b, sample_end=e, seed=seed, pipeline=args.pipeline), accum, stream)
+
+    def strong_step(k):
+        # frame k: its rows split between the ranks, then one reduce and the copy to the host
+        first, end = sharding.rank_rows(rank, world_size, args.rows)
+        accum.zero_()
+        if end > first:
+            scene.render_device(cam, rt.render_opts(cam, sample_begin=first * rows, sample_end=end * rows,
+                                                    seed=rt.scenes.PATH_SEED + 1000 + k, pipeline=args.pipeline), accum, stream)
+        return reduce_to_host()
+
+    def timed(step_fn, finish):
+        for k in range(args.warmup):
+            step_fn(k)
+        fence()
+        ctx.reset_stats()
+        accum.zero_()
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for k in range(args.steps):
+            last = step_fn(args.warmup + k)
+        if finish is not None:
+            last = finish()
+        fence()
+        dt = time.perf_counter() - t0
+        st = ctx.stats()
+        seg, paths = float(st["segments"]), float(st["paths"])
+        if dist is not None:
+            t = torch.tensor([dt, seg, paths], dtype=torch.float64, device=coll)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dt, seg, paths = float(tmax[0]), float(t[1]), float(t[2])
+        return dt, seg, paths, last
+
+    results = {}
+    if args.scaling in ("both", "weak") or world_size == 1:
+        results["weak"] = timed(weak_step, reduce_to_host)
+    if world_size > 1 and args.scaling in ("both", "strong"):
+        results["strong"] = timed(strong_step, None)
+    mode = "weak" if "weak" in results else "strong"
+    dt, segments, paths, host = results[mode]
 
     if rank == 0:
-        assert bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
-        assert paths == npix * rows * args.rows * args.steps * world_size
-        # Device-side timing of every traversal / shading launch (the library takes the wall clock of the first block in
-        # and the last block out), rank 0.  The roofline entry is for whichever of the two took more GPU time.
-        fused = st["traverse_launches"] == 0
-        # Shading kernel, per queue entry: the sort reads the hit kind and the path's coordinates (4 + 12 B); an entry
-        # the roulette does not end there is read in full (ray 56 + throughput 24 + ids 12 + hit 16 = 108 B) and then
-        # either written back as a survivor (92 B) or ends with three pixel atomics (24 B).  A path ends exactly once.
-        p_survive = 1.0 - paths / max(1.0, segments)
-        p_drop = st.get("roulette_drops", 0) / max(1.0, st["segments"])
-        shade_bytes = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
-        cands = [("k_render_fused", st["render_ms"], st["launches"], BOUNCE_BYTES, None)] if fused else [
-            # a new camera path (one segment in paths / segments) is not read at all: the world-program launch makes its
-            # camera ray, writes its queue record (92 B) and its hit (16 B) and walks it from the start of the program
-            ("k_wf_traverse<true,false,1,true>", st["traverse_ms"], st["traverse_launches"],
-             TRAVERSE_BYTES + (108.0 - TRAVERSE_BYTES) * paths / max(1.0, segments) if st["head_launches"] else TRAVERSE_BYTES_UNSPLIT,
-             TRAVERSE_PMC_TRAFFIC_PER_SEGMENT),
-            ("k_wf_shade", st["shade_ms"], st["shade_launches"], shade_bytes, SHADE_PMC_TRAFFIC_PER_SEGMENT)]
-        rl = []
-        for name, ms, n_launch, seg_bytes, pmc in cands:
-            kernel_ms = ms / max(1, n_launch)
-            seg_per_launch = st["segments"] / max(1, n_launch)
-            achieved = seg_per_launch * seg_bytes / (kernel_ms * 1e-3) / 1e9
-            rl.append({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": None if pmc is None else seg_per_launch * pmc,
-                       "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r1_pmc_summary.txt",
-                       "kernel": name, "kernel_ms": kernel_ms, "launches": n_launch, "segments_per_launch": seg_per_launch,
-                       "algorithmic_bytes_per_segment": seg_bytes, "algorithmic_bytes_per_launch": seg_per_launch * seg_bytes,
-                       "gpu_ms": ms})
-        rl.sort(key=lambda r: -r["gpu_ms"])
-        roofline = dict(rl[0])
-        roofline.update({
-            "kernel_ms_source": "wall clock of the first block in / last block out of every launch, taken on the device "
-                                "(a launch shares the GPU with the launches of the other pipelines)",
-            "whole_bounce": {"algorithmic_bytes_per_segment": BOUNCE_BYTES,
-                             "achieved": segments / world_size / dt * BOUNCE_BYTES / 1e9, "unit": "GB/s",
-                             "frac": segments / world_size / dt * BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS},
-            "other_kernels": rl[1:],
-            "note": "f64 VALU/latency-bound code; the HBM streams of rays, hits and path state are the only bytes it must move; "
-                    "four pipelines run side by side, so a launch does not have the GPU to itself"})
+        assert host is not None and bool(torch.isfinite(host).all()), "non-finite radiance in the accumulator"
+        per_step = npix * rows * args.rows
+        assert paths == per_step * args.steps * (world_size if mode == "weak" else 1), (paths, per_step)
         out = {
             "metric": "Msamples/s (node) final scene 800x800", "value": paths / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": mode, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"final scene (final_scene.rs) 800x800, depth 75, step = one render call of {args.rows} of the "
-                                   f"70 rows of the 4900-sample stratification = {npix * rows * args.rows / 1e6:.1f}M camera "
-                                   "paths per GPU per step",
-                       "scene_seed": hex(rt.scenes.SCENE_SEED), "sharding": "sample rows per rank, one reduce(sum) of the f64 accumulator",
+                                   f"70 rows of the 4900-sample stratification = {per_step / 1e6:.1f}M camera paths",
+                       "weak": "every (rank, step) renders that batch with its own path seed; one reduce(sum) of the f64 "
+                               "accumulators and the copy to the host at the end of the timed region",
+                       "strong": "every step is ONE such batch, its rows split between the ranks; reduce(sum) and copy to the "
+                                 "host after every step",
+                       "scene_seed": hex(rt.scenes.SCENE_SEED),
                        "pipelines_per_gpu": int(os.environ.get("RTX_WF_LANES", "4")),
                        "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 27)))},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
-            "roofline": roofline,
         }
+        if "strong" in results and mode != "strong":
+            sdt, sseg, spaths, shost = results["strong"]
+            assert shost is not None and bool(torch.isfinite(shost).all()) and spaths == per_step * args.steps
+            out["strong_scaling"] = {"value": spaths / sdt / 1e6, "unit": "Msamples/s", "ms_per_step": sdt / args.steps * 1e3,
+                                     "steps": args.steps, "Msegments_per_s": sseg / sdt / 1e6,
+                                     "what": "one 800x800 frame per step over all ranks, reduce + copy to the host per frame"}
+    # rank 0 alone: exclusive kernel durations for the roofline block (the other ranks wait at the barrier below)
+    if rank == 0:
+        out["roofline"] = roofline_block(rt, ctx, scene, cam, accum, stream, min(args.roofline_rows, rows),
+                                         segments / world_size / dt, torch)
         if world_size == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(threads, samples=args.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(samples=args.cpu_samples)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     scene.close()
     ctx.close()

@@ -202,6 +202,9 @@ typedef struct rtx_stats { /* totals since context creation */
   uint64_t shade_launches;
   uint64_t roulette_drops; /* wavefront pipeline: hits whose path the roulette (camera.rs:227-231) ended before shading;
                             * the shading kernel reads only their hit kind and path coordinates */
+  uint64_t iterations;     /* wavefront pipeline: iterations enqueued = launches of EACH of its kernels, the ones that
+                            * found an empty queue included (traverse_launches and shade_launches count only launches
+                            * that had work; a profiler counts every launch) */
 } rtx_stats;
 
 typedef struct rtx_context rtx_context;
@@ -227,8 +230,13 @@ rtx_status rtx_camera_initialize(rtx_camera_desc* cam);
 
 /* The hot path: Camera::render's pixel/sample loops and ray_color (camera.rs:133-268, 288-313) for the given sample
  * range and pixel rectangle.  ADDS per-pixel radiance sums into accum (image_width*image_height*3 doubles, row-major
- * RGB).  rtx_render takes a host accumulator; rtx_render_device takes a device pointer and a hipStream_t (NULL =
- * default stream) and is asynchronous with respect to the host. */
+ * RGB).  rtx_render takes a host accumulator and returns when it holds the result.  rtx_render_device takes a device
+ * pointer and a hipStream_t (NULL = default stream): the accumulator is complete once work enqueued on that stream
+ * after the call runs (or the stream is synchronised).  The call itself BLOCKS the host for most of the render: the
+ * wavefront pipeline enqueues iterations in chunks and waits for the counters of the chunk before last to learn
+ * whether paths are left; only the last chunk is still in flight when it returns.  Calls on one context are ordered
+ * one after the other on the GPU whatever streams they are given (they share the context's workspace and
+ * statistics); calls on different contexts that add into the same accumulator must be ordered by the caller. */
 rtx_status rtx_render(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_render_opts* opts, double* accum_host);
 rtx_status rtx_render_device(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_render_opts* opts,
                              double* accum_dev, void* hip_stream);

@@ -823,6 +823,12 @@ static thread_local std::string g_error;
 struct TimedSpan { hipEvent_t e0, e1; int what; };  // what: 0 = whole render call, 1 = world-program traversal, 2 = deferred section, 3 = head section
 
 #define RT_WF_MAX_LANES 8
+struct WfBuffers {                 // device memory of one wavefront pipeline
+  WfQueue q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  WfHits hits = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t* defer = nullptr;       // queue indices of the rays that entered the deferred section
+  WfCounters* c = nullptr;
+};
 struct rtx_context {
   int device = 0;
   int n_cus = 256;
@@ -830,24 +836,26 @@ struct rtx_context {
   std::string error;
   unsigned long long* d_counters = nullptr;  // paths, queue entries traversed, pdf_probes, roulette drops, dead entries among those traversed
   double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0, shade_ms = 0.0;
-  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0;
+  uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0, iterations = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
   std::vector<hipEvent_t> free_events;
   // wavefront workspace (allocated on first use, kept for the context's lifetime): up to RT_WF_MAX_LANES independent pipelines
   bool wf_ready = false;
-  struct WfLane {
+  struct WfLane : WfBuffers {
     uint32_t cap = 0;              // paths in flight its buffers hold
     std::vector<void*> allocs;
-    WfQueue q[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    WfHits hits = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t* defer = nullptr;     // queue indices of the rays that entered the deferred section
-    WfCounters* c = nullptr;
     WfCounters* host = nullptr;    // pinned, two slots
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipStream_t stream = nullptr;  // the second pipeline runs on a stream of its own
     hipEvent_t joined = nullptr;
   } wf[RT_WF_MAX_LANES];
   hipEvent_t wf_fork = nullptr;
+  // Render calls of one context share its workspace (queues, counters, statistics), whatever stream each is given:
+  // every call first makes its stream wait for the end of the one before it.
+  hipEvent_t call_done = nullptr;
+  bool call_recorded = false;
+  double* host_accum_dev = nullptr;  // rtx_render's device copy of the caller's host accumulator; grows, never shrinks
+  size_t host_accum_len = 0;
 };
 
 struct rtx_scene {
@@ -1022,21 +1030,30 @@ static const size_t kLdsBudget = 160 * 1024 - 4096;  // the tuning build keeps 4
 static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, one persistent workgroup per CU
 #endif
 
+// Every traversal kernel instantiation that is launched with dynamic LDS (the staged program, the waves' defer
+// buffers, the lanes' stacks of the nearer-child-first walk: up to the whole 160 KiB) is given that limit once, when
+// the first context is created.
+static hipError_t wf_set_lds_limits() {
+  const void* kernels[] = {
+      (const void*)k_wf_traverse<true, false, MEDIA_NONE>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, (const void*)k_wf_traverse<true, false, MEDIA_ALL>,
+      (const void*)k_wf_traverse<true, false, MEDIA_NONE, true>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES, true>, (const void*)k_wf_traverse<true, false, MEDIA_ALL, true>,
+      (const void*)k_wf_traverse<false, false, MEDIA_NONE>, (const void*)k_wf_traverse<false, false, MEDIA_SPHERES>, (const void*)k_wf_traverse<false, false, MEDIA_ALL>,
+      (const void*)k_wf_traverse<true, true, MEDIA_NONE>, (const void*)k_wf_traverse<false, true, MEDIA_NONE>,
+      (const void*)k_wf_stream<true, false, 0>, (const void*)k_wf_stream<false, false, 0>, (const void*)k_wf_stream<true, false, 2>, (const void*)k_wf_stream<false, false, 2>,
+      (const void*)k_wf_stream<true, true, 0>, (const void*)k_wf_stream<false, true, 0>, (const void*)k_wf_stream<true, true, 1>, (const void*)k_wf_stream<false, true, 1>,
+      (const void*)k_wf_stream<true, true, 2>, (const void*)k_wf_stream<false, true, 2>};
+  for (const void* k : kernels) {
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // Workspace of pipeline `lane` for at least `want` paths in flight (a multiple of 256).  Buffers only grow; they are
-// kept for the context's lifetime.
-static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
+// kept for the context's lifetime.  *oom is set when device memory ran out (the lane is then left without buffers).
+static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want, bool* oom) {
+  *oom = false;
   if (!ctx->wf_ready) {
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, true, MEDIA_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_SPHERES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_traverse<true, false, MEDIA_ALL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*)k_wf_stream<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->wf_fork, hipEventDisableTiming));
     ctx->wf_ready = true;
   }
@@ -1053,18 +1070,173 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
   for (void* p : L.allocs) (void)hipFree(p);
   L.allocs.clear();
   L.cap = 0;
-  auto A = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) L.allocs.push_back(*p); return e; };
+  hipError_t err = hipSuccess;
+  auto A = [&](void** p, size_t bytes) { if (err == hipSuccess) { err = hipMalloc(p, bytes); if (err == hipSuccess) L.allocs.push_back(*p); } };
   for (int k = 0; k < 2; ++k) {
-    HIP_TRY(ctx, A((void**)&L.q[k].f, (size_t)want * 10 * sizeof(double)));
-    HIP_TRY(ctx, A((void**)&L.q[k].u, (size_t)want * 3 * sizeof(uint32_t)));
+    A((void**)&L.q[k].f, (size_t)want * 10 * sizeof(double));
+    A((void**)&L.q[k].u, (size_t)want * 3 * sizeof(uint32_t));
   }
-  HIP_TRY(ctx, A((void**)&L.hits.t, (size_t)want * sizeof(double)));
-  HIP_TRY(ctx, A((void**)&L.hits.kind_idx, (size_t)want * sizeof(uint32_t)));
-  HIP_TRY(ctx, A((void**)&L.hits.ctx, (size_t)want * sizeof(uint32_t)));
-  HIP_TRY(ctx, A((void**)&L.hits.uv, (size_t)want * 2 * sizeof(double)));
-  HIP_TRY(ctx, A((void**)&L.defer, (size_t)want * sizeof(uint32_t)));
+  A((void**)&L.hits.t, (size_t)want * sizeof(double));
+  A((void**)&L.hits.kind_idx, (size_t)want * sizeof(uint32_t));
+  A((void**)&L.hits.ctx, (size_t)want * sizeof(uint32_t));
+  A((void**)&L.hits.uv, (size_t)want * 2 * sizeof(double));
+  A((void**)&L.defer, (size_t)want * sizeof(uint32_t));
+  if (err != hipSuccess) {
+    for (void* p : L.allocs) (void)hipFree(p);
+    L.allocs.clear();
+    if (err == hipErrorOutOfMemory) { (void)hipGetLastError(); *oom = true; }
+    return fail(ctx, RTX_ERR_HIP, std::string("wavefront workspace of ") + std::to_string(want) + " paths: " + hipGetErrorString(err));
+  }
   L.cap = want;
   return RTX_OK;
+}
+
+static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
+  static unsigned v = 0;
+  if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
+  return v;
+}
+
+// How one iteration of the wavefront loop is launched for a given scene and queue capacity: which sections are walked
+// as streams, what each traversal kernel stages in LDS, which instantiation serves the world program.
+struct WfPlan {
+  Scene dev;                 // the scene as the traversal kernels see it (head_end, fresh_in_main set for this plan)
+  uint32_t cap = 0;
+  uint32_t head_end = 0, tail_begin = 0;
+  size_t head_bytes = 0, tail_bytes = 0, main_bytes = 0, defer_bytes = 0, near_stack_bytes = 0, near_head_stack = 0;
+  bool head_lds = false, tail_lds = false, main_lds = false, stream_tail = false;
+  bool near_lds = false, near_global = false, near_quads = false, near_head_lds = false, near_head_global = false;
+  bool skip_main = false;
+  void (*k_main)(Scene, uint32_t, unsigned long long, WfCounters*, WfQueue, WfHits, uint32_t*, unsigned long long*, rtx_camera_desc, WfFrame) = nullptr;
+  unsigned trav_blocks = 0, gen_blocks = 0, shade_blocks = 0;
+};
+
+static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
+  const rtx_context* ctx = sc->ctx;
+  WfPlan P;
+  P.cap = cap;
+  // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
+  // defer buffers; the deferred section's own program
+  const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
+  P.tail_begin = tail_begin;
+  // Stream walks (k_wf_stream) of the head and of the deferred section: lanes take the next ray as soon as theirs leaves
+  // the section.  Measured on the final scene: one pipeline 1827 Msamples/s streamed against 1523 with the sections
+  // walked per ray inside the world-program kernel, two pipelines 1906 against 1597; a section walked from global
+  // memory gains more (stress scene: +34 %).  So sections are streamed by default; RTX_WF_STREAM=0 streams none,
+  // 2 only the head, 3 only the deferred section.
+  const char* stream_env = getenv("RTX_WF_STREAM");
+  const int stream_mode = stream_env ? atoi(stream_env) : -1;  // -1: by size
+  P.head_bytes = sc->dev.head_end ? (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 : 0;
+  P.head_lds = P.head_bytes <= kLdsBudget;
+  P.tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
+  P.tail_lds = P.tail_bytes <= kLdsBudget;
+  const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
+  P.stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
+  // Sections that are binary trees of boxes over leaf records can be walked nearer child first (walk_stream_near);
+  // each lane's stack (one unit position per tree level) lives in LDS.  By default (RTX_WF_NEAR=1) the deferred
+  // section is, and the head section when it is too large for LDS: the stress scene's BVH of 1 M spheres and quads
+  // (20 levels, walked from global memory) goes from 49.6 to 76.9 Msamples/s, while the 400 boxes of the final
+  // scene's ground are slower that way (10 sample rows: 1957 and 1963 Msamples/s against 2004 and 2026 in the fixed
+  // order; most rays meet the ground from above, the first box they enter holds their hit in either order, and the
+  // walk pays for two box tests per step and the stack).  RTX_WF_NEAR=0 keeps the reference's left-to-right order
+  // everywhere, 2 walks every section of the shape nearer child first.
+  const char* near_env = getenv("RTX_WF_NEAR");
+  const int near_mode = near_env ? atoi(near_env) : 1;
+  const bool near_ok = P.stream_tail && sc->dev.tail_near_depth > 0 && near_mode != 0;
+  P.near_stack_bytes = (size_t)sc->dev.tail_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
+  P.near_lds = near_ok && P.tail_lds && P.tail_bytes + P.near_stack_bytes <= kLdsBudget;
+  P.near_global = near_ok && !P.tail_lds && P.near_stack_bytes <= kLdsBudget;
+  P.near_quads = sc->dev.tail_near_quads != 0;
+  const bool near_head_ok = stream_head && sc->dev.head_near_depth > 0 && (near_mode == 2 || (near_mode == 1 && !P.head_lds));
+  P.near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
+  P.near_head_lds = near_head_ok && P.head_lds && P.head_bytes + P.near_head_stack <= kLdsBudget;
+  P.near_head_global = near_head_ok && !P.head_lds && P.near_head_stack <= kLdsBudget;
+  const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
+  P.head_end = head_end;
+  P.dev = sc->dev;
+  P.dev.head_end = head_end;
+  // New camera paths are coherent (a wave holds one stratified sample of an 8 x 8 pixel tile): the per-ray walk with its
+  // votes serves them better than the stream (final scene, camera rays only: 54.9 ms per 448 M rays through head and
+  // world program in one walk against 25.5 + 42.3 ms streamed and then walked).  When the head section fits LDS next to
+  // the rest of the world program, the head stream therefore covers the survivors only.  RTX_WF_FRESH=0 turns it off.
+  const char* fresh_env = getenv("RTX_WF_FRESH");
+  const bool fresh_in_main = head_end != 0 && !(fresh_env && atoi(fresh_env) == 0) &&
+                             (size_t)(tail_begin ? tail_begin : n_units) * 8 + (tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0) <= kLdsBudget;
+  // ... and makes their camera rays itself instead of reading them back from a ray generation launch (one pipeline:
+  // 2057 against 1947 Msamples/s; RTX_WF_FRESH=1 keeps the separate launch)
+  P.dev.fresh_in_main = fresh_in_main ? ((fresh_env && atoi(fresh_env) == 1) ? 1u : 2u) : 0u;
+  const uint32_t main_first = (head_end && !fresh_in_main && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
+  P.main_bytes = (size_t)((tail_begin ? tail_begin : n_units) - main_first) * 8;
+  P.defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
+  P.main_lds = P.main_bytes + P.defer_bytes <= kLdsBudget;
+  // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
+  const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
+  // without a head section every path starts at the start of the program anyway: the kernel only has to make the rays
+  if (head_end == 0 && P.main_lds && !(fresh_env && (atoi(fresh_env) == 0 || atoi(fresh_env) == 1))) P.dev.fresh_in_main = 2u;
+  const bool gen_in_main = P.dev.fresh_in_main == 2u;   // then main_lds holds (the whole world program fits LDS)
+  // A world that is one large BVH is all head section: the head stream leaves every path's closest hit in the hit
+  // arrays, and a world-program launch would only read and rewrite them (stress scene: 23 % of the GPU time).
+  P.skip_main = head_end != 0 && P.dev.fresh_in_main == 0u && sc->nothing_behind_head;
+  P.k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
+           : P.main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
+                        : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
+  const unsigned blocks256 = cap / 256;
+  P.trav_blocks = (unsigned)ctx->n_cus;
+  P.gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
+  P.shade_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 16u);
+  return P;
+}
+
+// One iteration on stream s: top the queue up, traverse (head section, world program, deferred section), shade.
+// B.q[cur] is read, B.q[cur ^ 1] receives the survivors.  timed: HIP event pairs around the section launches (they
+// create events when the context's pool is empty).
+static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera_desc* cam, const WfFrame& fr, unsigned long long seed,
+                                int use_lights, const WfBuffers& B, int cur, hipStream_t s, double* accum_dev, bool timed) {
+  rtx_context* ctx = sc->ctx;
+  const uint32_t cap = P.cap;
+  const Scene& dev = P.dev;
+  const dim3 tb(P.trav_blocks), tt(RT_TRAV_THREADS);
+  WfQueue qin = B.q[cur], qout = B.q[cur ^ 1];
+  ctx->iterations += 1;
+  hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, B.c, cap, fr.per_sample, ctx->d_counters, P.skip_main ? 1 : 0);
+  if (dev.fresh_in_main != 2u) hipLaunchKernelGGL(k_wf_raygen, dim3(P.gen_blocks), dim3(256), 0, s, *cam, fr, seed, cap, B.c, qin);
+  if (P.head_end) {  // the head section of the world program, streamed
+    TimedSpan sh;
+    const bool timed_head = timed && span_begin(ctx, s, sh, 3);
+    if (P.near_head_lds)
+      hipLaunchKernelGGL((k_wf_stream<true, false, 2>), tb, tt, P.head_bytes + P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.near_head_global)
+      hipLaunchKernelGGL((k_wf_stream<false, false, 2>), tb, tt, P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.head_lds)
+      hipLaunchKernelGGL((k_wf_stream<true, false, 0>), tb, tt, P.head_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else
+      hipLaunchKernelGGL((k_wf_stream<false, false, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer);
+    if (timed_head) span_end(ctx, s, sh);
+  }
+  if (!P.skip_main)
+    hipLaunchKernelGGL(P.k_main, tb, tt, (P.main_lds ? P.main_bytes : 0) + P.defer_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
+  if (P.tail_begin) {  // the deferred section for the rays that passed its root box
+    TimedSpan st;
+    const bool timed_tail = timed && span_begin(ctx, s, st, 2);
+    if (P.stream_tail && P.near_lds && P.near_quads)
+      hipLaunchKernelGGL((k_wf_stream<true, true, 2>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.stream_tail && P.near_lds)
+      hipLaunchKernelGGL((k_wf_stream<true, true, 1>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.stream_tail && P.near_global && P.near_quads)
+      hipLaunchKernelGGL((k_wf_stream<false, true, 2>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.stream_tail && P.near_global)
+      hipLaunchKernelGGL((k_wf_stream<false, true, 1>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.stream_tail && P.tail_lds)
+      hipLaunchKernelGGL((k_wf_stream<true, true, 0>), tb, tt, P.tail_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.stream_tail)
+      hipLaunchKernelGGL((k_wf_stream<false, true, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer);
+    else if (P.tail_lds)
+      hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
+    else
+      hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), tb, tt, 0, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
+    if (timed_tail) span_end(ctx, s, st);
+  }
+  hipLaunchKernelGGL(k_wf_shade, dim3(P.shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, B.c, qin, B.hits, qout, accum_dev, ctx->d_counters, sc->mat_class);
 }
 
 // The wavefront loop: [prepare, ray generation, traversal, shading+compaction] per iteration until every camera path
@@ -1078,12 +1250,7 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want) {
 // 3 x 32 M paths in flight 1960, 4 x 16 M 1731, 4 x 32 M 1933, 4 x 64 M 2058, 5: 1691, 6: 1675.  Default: one pipeline per
 // 4 M camera paths of the call, at most four, each holding at most 128 M paths (29.4 GB; 4 x 64 M 2189, 4 x 128 M 2231,
 // 3 x 96 M 2212) and no more than its share of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
-static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
-  static unsigned v = 0;
-  if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
-  return v;
-}
-
+// When device memory does not hold that workspace the capacity is halved until it does (down to 64 K paths).
 static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
   rtx_context* ctx = sc->ctx;
   const int n_samples = o->sample_end - o->sample_begin;
@@ -1100,78 +1267,16 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   }
   cap = (cap + 255u) & ~255u;
   if (per_sample + cap >= (1ull << 32)) return fail(ctx, RTX_ERR_UNSUPPORTED, "rtx_render: more than 2^32 pixels in one call");
-  for (int l = 0; l < n_lanes; ++l) {
-    rtx_status st = wf_ensure(ctx, l, cap);
-    if (st != RTX_OK) return st;
+  for (int l = 0; l < n_lanes;) {
+    bool oom = false;
+    rtx_status st = wf_ensure(ctx, l, cap, &oom);
+    if (st == RTX_OK) { ++l; continue; }
+    if (!oom || cap <= 65536u) return st;
+    cap = std::max(65536u, (cap / 2u + 255u) & ~255u);   // every pipeline of the call works with the same capacity
+    l = 0;
   }
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
-  // what each traversal kernel stages in LDS: the world program (up to the deferred section, if any) + the waves'
-  // defer buffers; the deferred section's own program
-  const uint32_t tail_begin = sc->dev.tail_begin, n_units = sc->dev.n_units;
-  // Stream walks (k_wf_stream) of the head and of the deferred section: lanes take the next ray as soon as theirs leaves
-  // the section.  Measured on the final scene: one pipeline 1827 Msamples/s streamed against 1523 with the sections
-  // walked per ray inside the world-program kernel, two pipelines 1906 against 1597; a section walked from global
-  // memory gains more (stress scene: +34 %).  So sections are streamed by default; RTX_WF_STREAM=0 streams none,
-  // 2 only the head, 3 only the deferred section.
-  const char* stream_env = getenv("RTX_WF_STREAM");
-  const int stream_mode = stream_env ? atoi(stream_env) : -1;  // -1: by size
-  const size_t head_bytes = sc->dev.head_end ? (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 : 0;
-  const bool head_lds = head_bytes <= kLdsBudget;
-  const size_t tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
-  const bool tail_lds = tail_bytes <= kLdsBudget;
-  const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
-  const bool stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
-  // Sections that are binary trees of boxes over leaf records can be walked nearer child first (walk_stream_near);
-  // each lane's stack (one unit position per tree level) lives in LDS.  By default (RTX_WF_NEAR=1) the deferred
-  // section is, and the head section when it is too large for LDS: the stress scene's BVH of 1 M spheres and quads
-  // (20 levels, walked from global memory) goes from 49.6 to 76.9 Msamples/s, while the 400 boxes of the final
-  // scene's ground are slower that way (10 sample rows: 1957 and 1963 Msamples/s against 2004 and 2026 in the fixed
-  // order; most rays meet the ground from above, the first box they enter holds their hit in either order, and the
-  // walk pays for two box tests per step and the stack).  RTX_WF_NEAR=0 keeps the reference's left-to-right order
-  // everywhere, 2 walks every section of the shape nearer child first.
-  const char* near_env = getenv("RTX_WF_NEAR");
-  const int near_mode = near_env ? atoi(near_env) : 1;
-  const bool near_ok = stream_tail && sc->dev.tail_near_depth > 0 && near_mode != 0;
-  const size_t near_stack_bytes = (size_t)sc->dev.tail_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
-  const bool near_lds = near_ok && tail_lds && tail_bytes + near_stack_bytes <= kLdsBudget;
-  const bool near_global = near_ok && !tail_lds && near_stack_bytes <= kLdsBudget;
-  const bool near_quads = sc->dev.tail_near_quads != 0;
-  const bool near_head_ok = stream_head && sc->dev.head_near_depth > 0 && (near_mode == 2 || (near_mode == 1 && !head_lds));
-  const size_t near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
-  const bool near_head_lds = near_head_ok && head_lds && head_bytes + near_head_stack <= kLdsBudget;
-  const bool near_head_global = near_head_ok && !head_lds && near_head_stack <= kLdsBudget;
-  const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
-  Scene dev = sc->dev;
-  dev.head_end = head_end;
-  // New camera paths are coherent (a wave holds one stratified sample of an 8 x 8 pixel tile): the per-ray walk with its
-  // votes serves them better than the stream (final scene, camera rays only: 54.9 ms per 448 M rays through head and
-  // world program in one walk against 25.5 + 42.3 ms streamed and then walked).  When the head section fits LDS next to
-  // the rest of the world program, the head stream therefore covers the survivors only.  RTX_WF_FRESH=0 turns it off.
-  const char* fresh_env = getenv("RTX_WF_FRESH");
-  const bool fresh_in_main = head_end != 0 && !(fresh_env && atoi(fresh_env) == 0) &&
-                             (size_t)(tail_begin ? tail_begin : n_units) * 8 + (tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0) <= kLdsBudget;
-  // ... and makes their camera rays itself instead of reading them back from a ray generation launch (one pipeline:
-  // 2057 against 1947 Msamples/s; RTX_WF_FRESH=1 keeps the separate launch)
-  dev.fresh_in_main = fresh_in_main ? ((fresh_env && atoi(fresh_env) == 1) ? 1u : 2u) : 0u;
-  const uint32_t main_first = (head_end && !fresh_in_main && sc->n_general_media == 0) ? ((head_end + 1u) & ~1u) : 0u;
-  const size_t main_bytes = (size_t)((tail_begin ? tail_begin : n_units) - main_first) * 8;
-  const size_t defer_bytes = tail_begin ? (size_t)(RT_TRAV_THREADS / 64) * RT_DEFER_SLOTS * sizeof(uint32_t) : 0;
-  const bool main_lds = main_bytes + defer_bytes <= kLdsBudget;
-  // the world-program kernel this scene needs: program in LDS or not, and what its media ask for
-  const int mm = sc->dev.n_media == 0 ? MEDIA_NONE : (sc->n_general_media == 0 ? MEDIA_SPHERES : MEDIA_ALL);
-  // without a head section every path starts at the start of the program anyway: the kernel only has to make the rays
-  if (head_end == 0 && main_lds && !(fresh_env && (atoi(fresh_env) == 0 || atoi(fresh_env) == 1))) dev.fresh_in_main = 2u;
-  const bool gen_in_main = dev.fresh_in_main == 2u;   // then main_lds holds (the whole world program fits LDS)
-  // A world that is one large BVH is all head section: the head stream leaves every path's closest hit in the hit
-  // arrays, and a world-program launch would only read and rewrite them (stress scene: 23 % of the GPU time).
-  const bool skip_main = head_end != 0 && dev.fresh_in_main == 0u && sc->nothing_behind_head;
-  auto k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
-              : main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
-                         : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
-  const unsigned blocks256 = cap / 256;
-  const unsigned trav_blocks = (unsigned)ctx->n_cus;
-  const unsigned gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
-  const unsigned shade_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 16u);
+  const WfPlan P = wf_make_plan(sc, cap);
   const unsigned long long seed = (unsigned long long)o->seed;
 
   struct Run { rtx_context::WfLane* L; hipStream_t s; WfFrame fr; int cur, k; bool done; };
@@ -1197,46 +1302,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
       for (int it = 0; it < chunk; ++it) {
-        WfQueue qin = L.q[r.cur], qout = L.q[r.cur ^ 1];
-        hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, L.c, cap, r.fr.per_sample, ctx->d_counters, skip_main ? 1 : 0);
-        if (dev.fresh_in_main != 2u) hipLaunchKernelGGL(k_wf_raygen, dim3(gen_blocks), dim3(256), 0, s, *cam, r.fr, seed, cap, L.c, qin);
-        if (head_end) {  // the head section of the world program, streamed
-          TimedSpan sh;
-          const bool timed_head = span_begin(ctx, s, sh, 3);
-          if (near_head_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, false, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes + near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (near_head_global)
-            hipLaunchKernelGGL((k_wf_stream<false, false, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_head_stack, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (head_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), head_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else
-            hipLaunchKernelGGL((k_wf_stream<false, false>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
-          if (timed_head) span_end(ctx, s, sh);
-        }
-        if (!skip_main)
-          hipLaunchKernelGGL(k_main, dim3(trav_blocks), dim3(RT_TRAV_THREADS), (main_lds ? main_bytes : 0) + defer_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
-        if (tail_begin) {  // the deferred section for the rays that passed its root box
-          TimedSpan st;
-          const bool timed_tail = span_begin(ctx, s, st, 2);
-          if (stream_tail && near_lds && near_quads)
-            hipLaunchKernelGGL((k_wf_stream<true, true, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (stream_tail && near_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, true, 1>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes + near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (stream_tail && near_global && near_quads)
-            hipLaunchKernelGGL((k_wf_stream<false, true, 2>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (stream_tail && near_global)
-            hipLaunchKernelGGL((k_wf_stream<false, true, 1>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), near_stack_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (stream_tail && tail_lds)
-            hipLaunchKernelGGL((k_wf_stream<true, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (stream_tail)
-            hipLaunchKernelGGL((k_wf_stream<false, true>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, L.c, qin, L.hits, L.defer);
-          else if (tail_lds)
-            hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), tail_bytes, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
-          else
-            hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), dim3(trav_blocks), dim3(RT_TRAV_THREADS), 0, s, dev, cap, seed, L.c, qin, L.hits, L.defer, ctx->d_counters, *cam, r.fr);
-          if (timed_tail) span_end(ctx, s, st);
-        }
-        hipLaunchKernelGGL(k_wf_shade, dim3(shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, L.c, qin, L.hits, qout, accum_dev, ctx->d_counters, sc->mat_class);
+        wf_launch_iteration(sc, P, cam, r.fr, seed, use_lights, L, r.cur, s, accum_dev, true);
         r.cur ^= 1;
       }
       hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
@@ -1259,12 +1325,23 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       if (ctx->pending.size() > 2048) drain_events(ctx);
     }
   }
-  // the caller's stream continues when every pipeline is through
+  // the caller's stream continues when every pipeline is through (the last chunk enqueued on each included)
   for (int l = 1; l < n_lanes; ++l) {
     HIP_TRY(ctx, hipEventRecord(runs[l].L->joined, runs[l].s));
     HIP_TRY(ctx, hipStreamWaitEvent(stream, runs[l].L->joined, 0));
   }
   return RTX_OK;
+}
+
+// Ordering of render calls of one context: the workspace, the counters and the statistics are the context's, so a
+// call given another stream than the one before it must not start before that one has ended.
+static hipError_t call_begin(rtx_context* ctx, hipStream_t stream) {
+  return ctx->call_recorded ? hipStreamWaitEvent(stream, ctx->call_done, 0) : hipSuccess;
+}
+static hipError_t call_end(rtx_context* ctx, hipStream_t stream) {
+  const hipError_t e = hipEventRecord(ctx->call_done, stream);
+  if (e == hipSuccess) ctx->call_recorded = true;
+  return e;
 }
 
 extern "C" {
@@ -1289,6 +1366,13 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
     return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
   }
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  hipError_t setup = wf_set_lds_limits();
+  if (setup == hipSuccess) setup = hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming);
+  if (setup != hipSuccess) {
+    const std::string why = std::string("rtx_context_create: device set-up failed: ") + hipGetErrorString(setup);
+    rtx_context_destroy(ctx);
+    return fail(nullptr, RTX_ERR_HIP, why);
+  }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) ctx->wall_clock_khz = (double)khz;
   *out = ctx;
@@ -1310,6 +1394,8 @@ void rtx_context_destroy(rtx_context* ctx) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
   }
   if (ctx->wf_fork) (void)hipEventDestroy(ctx->wf_fork);
+  if (ctx->call_done) (void)hipEventDestroy(ctx->call_done);
+  if (ctx->host_accum_dev) (void)hipFree(ctx->host_accum_dev);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   delete ctx;
 }
@@ -1387,6 +1473,7 @@ rtx_status rtx_render_device(rtx_scene* sc, const rtx_camera_desc* cam, const rt
     pipeline = (e && atoi(e) == RTX_PIPELINE_FUSED) ? RTX_PIPELINE_FUSED : RTX_PIPELINE_WAVEFRONT;
   }
   if (cam->max_depth > 0xFFFF) pipeline = RTX_PIPELINE_FUSED;  // the wavefront state packs depth and bounce into 16 bits each
+  HIP_TRY(ctx, call_begin(ctx, stream));
   TimedSpan sp;
   const bool timed = span_begin(ctx, stream, sp, 0);
   rtx_status st = RTX_OK;
@@ -1399,6 +1486,7 @@ rtx_status rtx_render_device(rtx_scene* sc, const rtx_camera_desc* cam, const rt
     st = render_wavefront(sc, cam, o, accum_dev, stream);
   }
   if (timed) span_end(ctx, stream, sp);
+  HIP_TRY(ctx, call_end(ctx, stream));
   if (ctx->pending.size() > 4096) drain_events(ctx);
   return st;
 }
@@ -1409,21 +1497,22 @@ rtx_status rtx_render(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_rende
   if (const char* why = validate_render(cam, o)) return fail(ctx, RTX_ERR_INVALID, std::string("rtx_render: ") + why);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n = (size_t)cam->image_width * (size_t)cam->image_height * 3;
-  double* d = nullptr;
-  HIP_TRY(ctx, hipMalloc((void**)&d, n * sizeof(double)));
-  rtx_status st = RTX_OK;
-  std::vector<double> tmp;
-  do {
-    if (hipMemset(d, 0, n * sizeof(double)) != hipSuccess) { st = fail(ctx, RTX_ERR_HIP, "rtx_render: hipMemset failed"); break; }
-    st = rtx_render_device(sc, cam, o, d, nullptr);
-    if (st != RTX_OK) break;
-    if (hipDeviceSynchronize() != hipSuccess) { st = fail(ctx, RTX_ERR_HIP, std::string("rtx_render: kernel failed: ") + hipGetErrorString(hipGetLastError())); break; }
-    tmp.resize(n);
-    if (hipMemcpy(tmp.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { st = fail(ctx, RTX_ERR_HIP, "rtx_render: copy back failed"); break; }
-    for (size_t k = 0; k < n; ++k) accum_host[k] += tmp[k];
-  } while (0);
-  (void)hipFree(d);
-  return st;
+  if (ctx->host_accum_len < n) {   // the device copy is the context's and only grows: no allocation per call
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (ctx->host_accum_dev) (void)hipFree(ctx->host_accum_dev);
+    ctx->host_accum_dev = nullptr; ctx->host_accum_len = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->host_accum_dev, n * sizeof(double)));
+    ctx->host_accum_len = n;
+  }
+  double* d = ctx->host_accum_dev;
+  HIP_TRY(ctx, hipMemset(d, 0, n * sizeof(double)));
+  rtx_status st = rtx_render_device(sc, cam, o, d, nullptr);
+  if (st != RTX_OK) return st;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, RTX_ERR_HIP, std::string("rtx_render: kernel failed: ") + hipGetErrorString(hipGetLastError()));
+  std::vector<double> tmp(n);
+  HIP_TRY(ctx, hipMemcpy(tmp.data(), d, n * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < n; ++k) accum_host[k] += tmp[k];
+  return RTX_OK;
 }
 
 rtx_status rtx_resolve_rgb8_device(rtx_context* ctx, const double* accum_dev, int width, int height, int spp, uint8_t* rgb_dev, void* hip_stream) {
@@ -1498,7 +1587,7 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
   out->head_ms = ctx->head_ms; out->head_launches = ctx->head_launches;
-  out->shade_ms = ctx->shade_ms; out->shade_launches = ctx->shade_launches;
+  out->shade_ms = ctx->shade_ms; out->shade_launches = ctx->shade_launches; out->iterations = ctx->iterations;
   return RTX_OK;
 }
 
@@ -1508,7 +1597,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 5 * sizeof(unsigned long long)));
-  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0;
+  ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0; ctx->iterations = 0;
   return RTX_OK;
 }
 

@@ -133,11 +133,19 @@ class Scene:
         _check(lib.rtx_render(self.handle, C.byref(cam), C.byref(opts), accum.ctypes.data_as(_capi.PD)), self.ctx.handle)
         return accum
 
-    def render_device(self, cam, opts, accum_tensor, stream=None):
-        """Device accumulator: a contiguous float64 CUDA tensor of H*W*3 elements; asynchronous."""
-        assert accum_tensor.is_cuda and accum_tensor.is_contiguous() and accum_tensor.element_size() == 8
-        assert accum_tensor.numel() == cam.image_height * cam.image_width * 3
-        _check(lib.rtx_render_device(self.handle, C.byref(cam), C.byref(opts), C.c_void_p(accum_tensor.data_ptr()),
+    @staticmethod
+    def _device_pointer(cam, accum):
+        """accum: a contiguous float64 CUDA tensor of H*W*3 elements, or a raw device address (int / c_void_p)."""
+        if hasattr(accum, "data_ptr"):
+            assert accum.is_cuda and accum.is_contiguous() and accum.element_size() == 8
+            assert accum.numel() == cam.image_height * cam.image_width * 3
+            return C.c_void_p(accum.data_ptr())
+        return accum if isinstance(accum, C.c_void_p) else C.c_void_p(int(accum))
+
+    def render_device(self, cam, opts, accum, stream=None):
+        """Device accumulator (rtx_render_device).  The result is complete once `stream` has been synchronised; the
+        call itself keeps the host busy for most of the render."""
+        _check(lib.rtx_render_device(self.handle, C.byref(cam), C.byref(opts), self._device_pointer(cam, accum),
                                      C.c_void_p(stream) if stream else None), self.ctx.handle)
 
     def first_hit(self, rays):

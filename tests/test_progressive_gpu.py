@@ -43,7 +43,7 @@ def test_stop_and_resume_gives_the_uninterrupted_image(tmp_path):
     # stop after two batches, then call again with the same checkpoint
     part, done = cam.render_progressive(world, lights, rows_per_batch=2, checkpoint=ckpt, progress=lambda r, n, s: r >= 4, save=False)
     assert done == 4 and os.path.exists(ckpt)
-    assert os.path.getsize(ckpt) == 48 + 64 * 64 * 3 * 8
+    assert os.path.getsize(ckpt) == 56 + 64 * 64 * 3 * 8   # header (magic, its size, frame, seed, scene identity) + accumulator
     resumed_rows = []
     cam.output_filename = str(tmp_path / "resumed.png")
     full, done = cam.render_progressive(world, lights, rows_per_batch=2, checkpoint=ckpt,
