@@ -241,6 +241,21 @@ rtx_status rtx_render(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_re
 rtx_status rtx_render_device(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_render_opts* opts,
                              double* accum_dev, void* hip_stream);
 
+/* rtx_render_device for callers that cannot allocate device memory or wait on the GPU: code under HIP graph capture,
+ * tight serving loops that render tile after tile, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * Same arguments, same paths and same result as rtx_render_device (up to the order of the f64 additions), but the
+ * call allocates nothing, creates no stream or event, reads nothing back and never blocks: it enqueues a fixed
+ * sequence of launches on hip_stream.  Its workspace (path queues, hit records, counters) is an array of
+ * RTX_NOALLOC_MAX_PATHS x 220 B + 2 KiB = 13.8 MiB that is part of the library's device code; every GPU holds one
+ * copy from the first context created on it until the process ends.  Limit: the call's camera paths - pixels of the
+ * rectangle x sample indices - must not exceed RTX_NOALLOC_MAX_PATHS (RTX_ERR_INVALID otherwise; split the rectangle
+ * or the sample range).  All such calls on one GPU share that GPU's array: calls of one context are ordered by the
+ * library; calls of different contexts (or processes' threads) on the same GPU that overlap in time race and must be
+ * ordered by the caller. */
+#define RTX_NOALLOC_MAX_PATHS 65536
+rtx_status rtx_render_device_noalloc(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_render_opts* opts,
+                                     double* accum_dev, void* hip_stream);
+
 /* color_to_rgb_with_samples (rendering/color.rs:16-52) over a whole accumulator: NaN -> 0, divide by the REQUESTED
  * samples_per_pixel (camera.rs:317), gamma 2, clamp to [0,0.999], quantise. */
 rtx_status rtx_resolve_rgb8(rtx_context* ctx, const double* accum_host, int width, int height, int samples_per_pixel,

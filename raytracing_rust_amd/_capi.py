@@ -15,6 +15,7 @@ f64x3 = f64 * 3
 RTX_OK, RTX_ERR_INVALID, RTX_ERR_NO_DEVICE, RTX_ERR_HIP, RTX_ERR_UNSUPPORTED, RTX_ERR_IO = range(6)
 NODE_BOX, NODE_SPHERE, NODE_QUAD, NODE_ENTER, NODE_EXIT, NODE_MEDIUM, NODE_NONE = 0, 1, 2, 3, 4, 5, 15
 PIPELINE_DEFAULT, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
+NOALLOC_MAX_PATHS = 65536
 
 
 class Node(C.Structure):
@@ -125,6 +126,7 @@ SYMBOLS = {
     "rtx_camera_initialize": (C.c_int, [C.POINTER(CameraDesc)]),
     "rtx_render": (C.c_int, [P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), PD]),
     "rtx_render_device": (C.c_int, [P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), P, P]),
+    "rtx_render_device_noalloc": (C.c_int, [P, C.POINTER(CameraDesc), C.POINTER(RenderOpts), P, P]),
     "rtx_resolve_rgb8": (C.c_int, [P, PD, C.c_int, C.c_int, C.c_int, C.POINTER(u8)]),
     "rtx_resolve_rgb8_device": (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "rtx_first_hit_aov": (C.c_int, [P, PD, C.c_size_t, PD, PD, C.POINTER(u32), C.POINTER(u32), C.POINTER(u8)]),

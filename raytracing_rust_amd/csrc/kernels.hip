@@ -1344,6 +1344,45 @@ static hipError_t call_end(rtx_context* ctx, hipStream_t stream) {
   return e;
 }
 
+// ------------------------------------------------- the entry point that allocates nothing ---
+// rtx_render_device_noalloc runs one wavefront pipeline whose whole workspace (both queues, the hit arrays, the defer
+// list and the counters) lives in g_noalloc_scratch, a device array that is part of the library's code object: every
+// GPU the library runs on holds its own copy from the moment the code object is loaded until the process ends.  Host
+// code never uses the array's name as an address; noalloc_setup asks the runtime for the array's device address once
+// per device and everything after that goes through that pointer.
+#define RT_NOALLOC_COUNTER_BYTES 2048u
+#define RT_NOALLOC_PER_PATH (2u * (10u * 8u + 3u * 4u) + 8u + 4u + 4u + 16u + 4u)   // two queues, hit (t, kind, ctx, uv), defer
+#define RT_NOALLOC_BYTES (RT_NOALLOC_COUNTER_BYTES + (size_t)RTX_NOALLOC_MAX_PATHS * RT_NOALLOC_PER_PATH)
+static_assert(sizeof(WfCounters) <= RT_NOALLOC_COUNTER_BYTES, "counters outgrew their part of the scratch array");
+static_assert(RTX_NOALLOC_MAX_PATHS % 256 == 0, "queue capacity must be a multiple of 256");
+static __device__ __align__(256) unsigned char g_noalloc_scratch[RT_NOALLOC_BYTES];
+#define RT_MAX_DEVICES 64
+static unsigned char* g_noalloc_ptr[RT_MAX_DEVICES];   // device address of each GPU's copy of the array
+
+static hipError_t noalloc_setup(int device) {   // with `device` current
+  if (device < 0 || device >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+  if (g_noalloc_ptr[device]) return hipSuccess;
+  void* p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+  if (e != hipSuccess) return e;
+  g_noalloc_ptr[device] = (unsigned char*)p;
+  return hipSuccess;
+}
+static WfBuffers noalloc_buffers(unsigned char* base) {
+  const size_t cap = RTX_NOALLOC_MAX_PATHS;
+  WfBuffers B;
+  unsigned char* p = base;
+  B.c = (WfCounters*)p; p += RT_NOALLOC_COUNTER_BYTES;
+  for (int k = 0; k < 2; ++k) { B.q[k].f = (double*)p; p += cap * 10 * sizeof(double); }
+  B.hits.t = (double*)p; p += cap * sizeof(double);
+  B.hits.uv = (double*)p; p += cap * 2 * sizeof(double);
+  for (int k = 0; k < 2; ++k) { B.q[k].u = (uint32_t*)p; p += cap * 3 * sizeof(uint32_t); }
+  B.hits.kind_idx = (uint32_t*)p; p += cap * sizeof(uint32_t);
+  B.hits.ctx = (uint32_t*)p; p += cap * sizeof(uint32_t);
+  B.defer = (uint32_t*)p; p += cap * sizeof(uint32_t);
+  return B;
+}
+
 extern "C" {
 
 const char* rtx_last_error(const rtx_context* ctx) { return ctx ? ctx->error.c_str() : g_error.c_str(); }
@@ -1368,6 +1407,7 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
   ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   hipError_t setup = wf_set_lds_limits();
   if (setup == hipSuccess) setup = hipEventCreateWithFlags(&ctx->call_done, hipEventDisableTiming);
+  if (setup == hipSuccess) setup = noalloc_setup(dev);
   if (setup != hipSuccess) {
     const std::string why = std::string("rtx_context_create: device set-up failed: ") + hipGetErrorString(setup);
     rtx_context_destroy(ctx);
@@ -1489,6 +1529,41 @@ rtx_status rtx_render_device(rtx_scene* sc, const rtx_camera_desc* cam, const rt
   HIP_TRY(ctx, call_end(ctx, stream));
   if (ctx->pending.size() > 4096) drain_events(ctx);
   return st;
+}
+
+rtx_status rtx_render_device_noalloc(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, void* hip_stream) {
+  if (!sc || !cam || !o || !accum_dev) return fail(sc ? sc->ctx : nullptr, RTX_ERR_INVALID, "rtx_render_device_noalloc: null argument");
+  rtx_context* ctx = sc->ctx;
+  if (const char* why = validate_render(cam, o)) return fail(ctx, RTX_ERR_INVALID, std::string("rtx_render_device_noalloc: ") + why);
+  const unsigned long long per_sample = (unsigned long long)(o->x1 - o->x0) * (unsigned long long)(o->y1 - o->y0);
+  const unsigned long long total = per_sample * (unsigned long long)(o->sample_end - o->sample_begin);
+  if (total > (unsigned long long)RTX_NOALLOC_MAX_PATHS)
+    return fail(ctx, RTX_ERR_INVALID, "rtx_render_device_noalloc: " + std::to_string(total) + " camera paths in one call, the limit is RTX_NOALLOC_MAX_PATHS = " +
+                                          std::to_string(RTX_NOALLOC_MAX_PATHS) + " (pixels of the rectangle x sample indices): split the call, or use rtx_render_device");
+  if (cam->max_depth > 0xFFFF) return fail(ctx, RTX_ERR_INVALID, "rtx_render_device_noalloc: max_depth above 65535");
+  if (total == 0 || cam->max_depth <= 0) return RTX_OK;   // a path of depth 0 is black (camera.rs:169-171)
+  unsigned char* base = (ctx->device >= 0 && ctx->device < RT_MAX_DEVICES) ? g_noalloc_ptr[ctx->device] : nullptr;
+  if (!base) return fail(ctx, RTX_ERR_HIP, "rtx_render_device_noalloc: the scratch array of this device was not set up");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(ctx, call_begin(ctx, stream));
+  const uint32_t cap = RTX_NOALLOC_MAX_PATHS;
+  const WfBuffers B = noalloc_buffers(base);
+  const WfPlan P = wf_make_plan(sc, cap);
+  WfFrame fr;
+  fr.x0 = o->x0; fr.y0 = o->y0; fr.w = o->x1 - o->x0; fr.h = o->y1 - o->y0; fr.sample_begin = o->sample_begin; fr.per_sample = (uint32_t)per_sample;
+  const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
+  const unsigned long long seed = (unsigned long long)o->seed;
+  // All camera paths of the call fit the queue at once: one iteration traces their first segment and shades it, and
+  // k_wf_finish (threshold = the whole queue) runs every survivor to its end.  Nothing is read back, so the host
+  // never waits and the sequence of launches does not depend on the data.  k_wf_begin clears every counter the array
+  // kept from the call before; queue entries are written before they are read.
+  hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, stream, B.c, total);
+  wf_launch_iteration(sc, P, cam, fr, seed, use_lights, B, 0, stream, accum_dev, false);
+  hipLaunchKernelGGL(k_wf_finish, dim3(cap / 256), dim3(256), 0, stream, sc->dev, *cam, cap, seed, use_lights, cap, B.c, B.q[1], accum_dev, ctx->d_counters);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, call_end(ctx, stream));
+  return RTX_OK;
 }
 
 rtx_status rtx_render(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_host) {

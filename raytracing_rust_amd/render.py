@@ -148,6 +148,11 @@ class Scene:
         _check(lib.rtx_render_device(self.handle, C.byref(cam), C.byref(opts), self._device_pointer(cam, accum),
                                      C.c_void_p(stream) if stream else None), self.ctx.handle)
 
+    def render_device_noalloc(self, cam, opts, accum, stream=None):
+        """rtx_render_device_noalloc: at most NOALLOC_MAX_PATHS camera paths per call, nothing allocated, never blocks."""
+        _check(lib.rtx_render_device_noalloc(self.handle, C.byref(cam), C.byref(opts), self._device_pointer(cam, accum),
+                                             C.c_void_p(stream) if stream else None), self.ctx.handle)
+
     def first_hit(self, rays):
         """rays: (n, 7) float64 = origin, direction, time.  Returns dict of t, normal, prim_id, mat_id, front."""
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)

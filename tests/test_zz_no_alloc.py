@@ -1,0 +1,74 @@
+"""GPU tier: rtx_render_device_noalloc, the render entry point that allocates nothing (its wavefront workspace is a
+device array inside the library), against rtx_render_device on the same inputs.
+
+Both trace the same paths (the RNG is addressed by pixel, sample and bounce); only the order of the f64 additions
+into a pixel differs, so the tolerance is 1e-11 relative, stated here.  The scratch array keeps the previous call's
+contents, hence two calls in a row, the second smaller than the first."""
+import numpy as np
+import pytest
+
+import raytracing_rust_amd as rt
+from raytracing_rust_amd import _capi, scenes
+import hiprt
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(scene, ctx, cam, opts):
+    n = cam.image_height * cam.image_width * 3
+    a, b = hiprt.DeviceArray(n), hiprt.DeviceArray(n)
+    ctx.reset_stats()
+    scene.render_device(cam, opts, a.ptr)
+    sa = ctx.stats()
+    ctx.reset_stats()
+    scene.render_device_noalloc(cam, opts, b.ptr)
+    sb = ctx.stats()
+    return a.numpy(), sa, b.numpy(), sb
+
+
+@pytest.mark.parametrize("name", ["final", "smoke", "cornell"])
+def test_noalloc_matches_render_device_twice_in_a_row(gpu_ctx, name):
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=96, spp=16, depth=30)
+    scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
+    # first call: exactly the limit (64 x 64 pixels x 16 sample indices); second: a smaller, ragged one
+    calls = [rt.render_opts(cam, rect=(8, 8, 72, 72), seed=41), rt.render_opts(cam, sample_begin=3, sample_end=10, rect=(5, 50, 45, 81), seed=42)]
+    assert (72 - 8) * (72 - 8) * 16 == _capi.NOALLOC_MAX_PATHS
+    for opts in calls:
+        a, sa, b, sb = _both(scene, gpu_ctx, cam, opts)
+        paths = (opts.x1 - opts.x0) * (opts.y1 - opts.y0) * (opts.sample_end - opts.sample_begin)
+        assert sa["paths"] == sb["paths"] == paths
+        assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+        assert a.sum() > 0
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
+def test_noalloc_rejects_calls_beyond_its_limit(gpu_ctx):
+    g = rt.Graph()
+    w, l, cam = scenes.build("cornell", g, width=96, spp=16, depth=10)
+    scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
+    acc = hiprt.DeviceArray(cam.image_height * cam.image_width * 3)
+    with pytest.raises(rt.RtxError) as e:
+        scene.render_device_noalloc(cam, rt.render_opts(cam, rect=(8, 8, 73, 72)), acc.ptr)
+    assert e.value.status == _capi.RTX_ERR_INVALID and "RTX_NOALLOC_MAX_PATHS" in str(e.value)
+    assert not acc.numpy().any()
+    scene.close()
+
+
+def test_noalloc_tiles_add_up_to_the_frame(gpu_ctx):
+    """A serving loop's use: the frame rendered tile by tile and sample batch by sample batch, every call within the
+    limit, all on one stream without a host wait in between."""
+    g = rt.Graph()
+    w, l, cam = scenes.build("quick", g, width=128, spp=16, depth=20)
+    scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
+    n = cam.image_height * cam.image_width * 3
+    full, tiles = hiprt.DeviceArray(n), hiprt.DeviceArray(n)
+    scene.render_device(cam, rt.render_opts(cam, seed=43), full.ptr)
+    stream = hiprt.Stream()
+    for y in range(0, 128, 64):
+        for x in range(0, 128, 64):
+            scene.render_device_noalloc(cam, rt.render_opts(cam, rect=(x, y, x + 64, y + 64), seed=43), tiles.ptr, stream.handle.value)
+    np.testing.assert_allclose(tiles.numpy(), full.numpy(), rtol=1e-11, atol=1e-13)
+    stream.close()
+    scene.close()
