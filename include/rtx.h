@@ -194,7 +194,9 @@ typedef struct rtx_stats { /* totals since context creation */
   double traverse_ms;    /* device time of the world-program traversal launches (wavefront pipeline): wall clock of the
                           * first block in / last block out of every launch, summed */
   uint64_t traverse_launches;
-  double tail_ms;        /* device time of the deferred-section traversal launches, when the program has one */
+  double tail_ms;        /* device time of the deferred-section traversal launches, when the program has one (HIP events
+                          * around each launch; taken only by calls that run a single pipeline, where launches do not
+                          * share the GPU; the launch counts are always kept) */
   uint64_t tail_launches;
   double head_ms;        /* device time of the head-section traversal launches, when the program has one */
   uint64_t head_launches;

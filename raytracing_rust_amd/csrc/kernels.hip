@@ -892,8 +892,8 @@ static void drain_events(rtx_context* ctx) {
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       if (p.what == 0) { ctx->render_ms += ms; ctx->last_kernel_ms = ms; ctx->launches += 1; }
       else if (p.what == 1) { ctx->traverse_ms += ms; ctx->traverse_launches += 1; }
-      else if (p.what == 2) { ctx->tail_ms += ms; ctx->tail_launches += 1; }
-      else { ctx->head_ms += ms; ctx->head_launches += 1; }
+      else if (p.what == 2) ctx->tail_ms += ms;   // the section launches themselves are counted where they are made
+      else ctx->head_ms += ms;
     }
     ctx->free_events.push_back(p.e0); ctx->free_events.push_back(p.e1);
   }
@@ -1201,6 +1201,7 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
   hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(1), 0, s, B.c, cap, fr.per_sample, ctx->d_counters, P.skip_main ? 1 : 0);
   if (dev.fresh_in_main != 2u) hipLaunchKernelGGL(k_wf_raygen, dim3(P.gen_blocks), dim3(256), 0, s, *cam, fr, seed, cap, B.c, qin);
   if (P.head_end) {  // the head section of the world program, streamed
+    ctx->head_launches += 1;
     TimedSpan sh;
     const bool timed_head = timed && span_begin(ctx, s, sh, 3);
     if (P.near_head_lds)
@@ -1216,6 +1217,7 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
   if (!P.skip_main)
     hipLaunchKernelGGL(P.k_main, tb, tt, (P.main_lds ? P.main_bytes : 0) + P.defer_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
   if (P.tail_begin) {  // the deferred section for the rays that passed its root box
+    ctx->tail_launches += 1;
     TimedSpan st;
     const bool timed_tail = timed && span_begin(ctx, s, st, 2);
     if (P.stream_tail && P.near_lds && P.near_quads)
@@ -1293,22 +1295,37 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
     if (l > 0) HIP_TRY(ctx, hipStreamWaitEvent(r.s, ctx->wf_fork, 0));
     hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, r.s, r.L->c, total);
   }
-  const int chunk = 8;
+  // Iterations are enqueued round robin, one per pipeline at a time, so that every pipeline has work on the GPU within
+  // the first few launches of the call (chunk after chunk per pipeline, a short call's last pipeline started when the
+  // first was nearly through: the host needs about a millisecond to enqueue a chunk).  HIP event pairs around the
+  // section launches only with a single pipeline: side by side the spans would overlap, and four event records per
+  // iteration are a fifth of the host's work here.
+  int chunk = 8;
+  if (const char* e = getenv("RTX_WF_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 64) chunk = v & ~1; }   // even: the queues swap roles every iteration
+  const bool timed_sections = n_lanes == 1;
   for (bool all_done = false; !all_done;) {
     all_done = true;
+    for (int it = 0; it < chunk; ++it)
+      for (int l = 0; l < n_lanes; ++l) {
+        Run& r = runs[l];
+        if (r.done) continue;
+        wf_launch_iteration(sc, P, cam, r.fr, seed, use_lights, *r.L, r.cur, r.s, accum_dev, timed_sections);
+        r.cur ^= 1;
+      }
     for (int l = 0; l < n_lanes; ++l) {
       Run& r = runs[l];
       if (r.done) continue;
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
-      for (int it = 0; it < chunk; ++it) {
-        wf_launch_iteration(sc, P, cam, r.fr, seed, use_lights, L, r.cur, s, accum_dev, true);
-        r.cur ^= 1;
-      }
       hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(&L.host[r.k & 1], L.c, sizeof(WfCounters), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipEventRecord(L.ev[r.k & 1], s));
+    }
+    for (int l = 0; l < n_lanes; ++l) {
+      Run& r = runs[l];
+      if (r.done) continue;
+      rtx_context::WfLane& L = *r.L;
       if (r.k > 0) {
         HIP_TRY(ctx, hipEventSynchronize(L.ev[(r.k - 1) & 1]));
         const WfCounters& c = L.host[(r.k - 1) & 1];
