@@ -101,3 +101,16 @@ def test_missing_library_raises_import_error():
     with pytest.raises(ImportError) as e:
         _capi.load_library(os.path.join(ROOT, "raytracing_rust_amd", "does_not_exist.so"))
     assert "no fallback" in str(e.value).lower()
+
+
+def test_rust_sys_crate_declares_the_same_abi():
+    """bindings/rust/rtx-sys/src/lib.rs cannot be compiled here (no cargo/rustc), so its text is checked instead: the
+    extern block names exactly the functions the headers declare, and the #[repr(C)] structs list the fields of the C
+    structs in the same order (layouts themselves are pinned against gcc above)."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "rtx-sys", "src", "lib.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (rtxh?_\w+)\s*\(", src))) == declared_functions()
+    for rust_name, cls in (("rtx_camera_desc", _capi.CameraDesc), ("rtx_render_opts", _capi.RenderOpts),
+                           ("rtx_stats", _capi.Stats), ("rtx_scene_desc", _capi.SceneDesc)):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % rust_name, src, flags=re.S).group(1)
+        fields = re.findall(r"pub (\w+)\s*:", body)
+        assert fields == [f for f, _ in cls._fields_], rust_name

@@ -48,6 +48,25 @@ def test_first_hit_aov_bit_exact_stress_scene(gpu_ctx):
     scene.close()
 
 
+def test_first_hit_aov_bit_exact_stress_scene_at_full_size(gpu_ctx):
+    """The synthetic stress configuration AT SIZE: 1 M spheres and quads in one BvhNode (a 70 MB hit program), the
+    3840 x 2160 camera, first hits on the pixel centres of every eighth pixel in both directions (480 x 270 rays)
+    bit-exact against the oracle's recursive BVH.  The product's tree is built on the GPU (rtx_bvh_leaf_order), the
+    oracle's by the recursion of bvh.rs:26-71."""
+    go, gp = H.oracle_graph(), rt.Graph()
+    gp.use_context(gpu_ctx)
+    wo, lo, cam_o = scenes.build("stress", go, prefix="orc_", lib=H.oracle_lib())
+    wp, lp, cam = scenes.build("stress", gp)
+    assert bytes(cam_o) == bytes(cam) and (cam.image_width, cam.image_height) == (3840, 2160)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    rays = rt.pixel_center_rays(cam, time=0.5).reshape(2160, 3840, 7)[4::8, 4::8].reshape(-1, 7)
+    assert rays.shape[0] == 480 * 270
+    ref = H.oracle_first_hit(go, wo, rays)
+    H.assert_aov_equal(ref, scene.first_hit(rays), "stress 1M")
+    assert np.isfinite(ref["t"]).sum() > 50000
+    scene.close()
+
+
 @pytest.mark.parametrize("recipe", recipes.ALL, ids=lambda r: r.__name__)
 def test_first_hit_aov_bit_exact_recipes(gpu_ctx, recipe):
     """Random and edge-case graphs: nested transforms, BVHs of mixed leaves, ties, axis-parallel rays, empty lists."""
