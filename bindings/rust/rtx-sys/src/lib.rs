@@ -49,7 +49,7 @@ pub struct rtx_stats {
     pub tail_ms: f64, pub tail_launches: u64,
     pub head_ms: f64, pub head_launches: u64,
     pub shade_ms: f64, pub shade_launches: u64,
-    pub roulette_drops: u64, pub iterations: u64,
+    pub roulette_drops: u64, pub order_redos: u64, pub iterations: u64,
 }
 
 /// The flat scene description; produced by rtxh_flatten, consumed by rtx_scene_create.  A binding only passes it on,

@@ -204,6 +204,8 @@ typedef struct rtx_stats { /* totals since context creation */
   uint64_t shade_launches;
   uint64_t roulette_drops; /* wavefront pipeline: hits whose path the roulette (camera.rs:227-231) ended before shading;
                             * the shading kernel reads only their hit kind and path coordinates */
+  uint64_t order_redos;    /* rays a nearer-child-first walk could not vouch for (a hit on the boundary of its own bounding
+                            * box, or a box culled by a hair) and that were walked again in the reference's order */
   uint64_t iterations;     /* wavefront pipeline: iterations enqueued = launches of EACH of its kernels, the ones that
                             * found an empty queue included (traverse_launches and shade_launches count only launches
                             * that had work; a profiler counts every launch) */
@@ -248,7 +250,7 @@ rtx_status rtx_render_device(rtx_scene* scene, const rtx_camera_desc* cam, const
  * Same arguments, same paths and same result as rtx_render_device (up to the order of the f64 additions), but the
  * call allocates nothing, creates no stream or event, reads nothing back and never blocks: it enqueues a fixed
  * sequence of launches on hip_stream.  Its workspace (path queues, hit records, counters) is an array of
- * RTX_NOALLOC_MAX_PATHS x 220 B + 2 KiB = 13.8 MiB that is part of the library's device code; every GPU holds one
+ * RTX_NOALLOC_MAX_PATHS x 220 B + 4 KiB = 13.8 MiB that is part of the library's device code; every GPU holds one
  * copy from the first context created on it until the process ends.  Limit: the call's camera paths - pixels of the
  * rectangle x sample indices - must not exceed RTX_NOALLOC_MAX_PATHS (RTX_ERR_INVALID otherwise; split the rectangle
  * or the sample range).  All such calls on one GPU share that GPU's array: calls of one context are ordered by the

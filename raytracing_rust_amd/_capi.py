@@ -108,7 +108,7 @@ class Stats(C.Structure):
     _fields_ = [("paths", u64), ("segments", u64), ("pdf_probes", u64), ("render_ms", f64), ("launches", u64),
                 ("last_kernel_ms", f64), ("traverse_ms", f64), ("traverse_launches", u64), ("tail_ms", f64),
                 ("tail_launches", u64), ("head_ms", f64), ("head_launches", u64), ("shade_ms", f64), ("shade_launches", u64),
-                ("roulette_drops", u64), ("iterations", u64)]
+                ("roulette_drops", u64), ("order_redos", u64), ("iterations", u64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p)

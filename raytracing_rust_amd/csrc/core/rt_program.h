@@ -108,7 +108,7 @@ struct CompiledProgram {
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
-    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr;
+    S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr; S.near_margin = RT_NEAR_MARGIN;
     return S;
   }
 

@@ -69,6 +69,7 @@ struct Scene : rtx_scene_desc {
   // wavefront shading kernel points them at LDS
   const rtx_quad* light_quads;
   const rtx_sphere* light_spheres;
+  double near_margin;   // relative margin of the nearer-child-first walk's order-dependence watch (RT_NEAR_MARGIN by default)
 };
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
@@ -652,6 +653,7 @@ RT_HD bool hit_any(const Hit& h) { return RTX_NODE_KIND(h.kind_idx) != RTX_NODE_
 //   Ray source: ray(id) (origin()/dir() as for walk_program), time(id)
 //   void start(id, tmax, kind, ctx)     the closest hit known before the section (tmax = RT_INF, kind NONE if none)
 //   void commit(id, tmax, kind, ctx)    the closest hit after the section
+//   void note_redo()                    (walk_stream_near) a ray is walked a second time, in the reference's order
 // Scheduling: box steps run in a tight loop while the lanes on boxes outweigh the lanes waiting on a leaf
 // (RT_STREAM_LEAF_BIAS box lanes count like one waiting lane: a leaf test costs several box tests) and fewer than
 // RT_STREAM_REFILL lanes are out of work; leaves are served largest class first.
@@ -812,6 +814,32 @@ RT_HD bool slab_hit_entry(const double* b, const LRay& r, double tmin, double tm
   entry = tmin;
   return !(tmax <= tmin);
 }
+// The same test for the nearer-child-first walk: also tells whether a box that FAILS fails only just - it would pass
+// with an upper bound larger by the relative margin RT_NEAR_MARGIN.  The decision itself is slab_hit's, bit for bit.
+#ifndef RT_NEAR_MARGIN
+#define RT_NEAR_MARGIN 1e-9
+#endif
+RT_HD bool slab_hit_entry_margin(const double* b, const LRay& r, double tmin, double tmax, double margin, double& entry, bool& close_call) {
+  const uint32_t nx = r.inv.x >= 0.0 ? 0u : 3u, ny = r.inv.y >= 0.0 ? 0u : 3u, nz = r.inv.z >= 0.0 ? 0u : 3u;
+  const double bnx = b[nx], bfx = b[3u - nx], bny = b[1u + ny], bfy = b[4u - ny], bnz = b[2u + nz], bfz = b[5u - nz];
+  double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
+  double nry = (bny - r.o.y) * r.inv.y, fry = (bfy - r.o.y) * r.inv.y;
+  double nrz = (bnz - r.o.z) * r.inv.z, frz = (bfz - r.o.z) * r.inv.z;
+  if (r.skip & 7u) {
+    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
+    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
+    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
+  }
+  const double tmax_in = tmax;
+  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
+  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
+  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
+  entry = tmin;
+  const bool pass = !(tmax <= tmin);
+  // failed because of the upper bound alone (the far planes lie behind the entry), and by less than the margin
+  close_call = !pass && tmax == tmax_in && tmax_in + tmax_in * margin > tmin;
+  return pass;
+}
 // Sphere::hit for a static sphere with an inclusive upper bound: a root equal to tmax is reported, so that the caller
 // can resolve the tie by program order (sphere_s_hit_t is this with the tie always lost, sphere.rs:99-101).
 RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, double tmin, double tmax, double& t) {
@@ -869,6 +897,16 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   const int bias = AHEAD ? RT_NEAR_LEAF_BIAS : RT_NEAR_LEAF_BIAS_FAR, bias_den = AHEAD ? 1 : RT_NEAR_LEAF_BIAS_FAR_DEN;
   const double tmin = 0.001;
   bool have = false, single = false, best_quad = false;
+  // Order-dependence watch.  The closest hit is the same in every visiting order as long as (a) every candidate hit
+  // lies behind the entry of the innermost box around its primitive, t > entry (then a box is only ever culled together
+  // with hits that lie behind the upper bound that culled it), and (b) no box is culled by a hair.  Rounding can break
+  // (a) where a surface touches its own box (the six axis extremes of a sphere): the box test then depends on the bound
+  // the order has reached.  A ray that meets either case within the margin is not committed: its lane walks it once
+  // more from the start in the REFERENCE's order (fixed_mode: the left child first whenever it passes; the right one,
+  // tested together with it, waits on the stack and is tested again with the bound the left subtree leaves behind,
+  // which is when and how bvh.rs:94-102 tests it).
+  bool suspect = false, fixed_mode = false;
+  double leaf_entry_hi = -RT_INF;   // entry of the last box this lane went through, plus the margin
   uint32_t id = 0, i = begin, end = 0xFFFFFFFFu, sp = 0, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
   uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
   double tmax = RT_INF;
@@ -877,6 +915,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
   // a hit at t from the primitive at program position pos: does it replace the best one so far?
   auto wins = [&](double t, uint32_t pos, bool quad) {
+    if (!fixed_mode && t <= leaf_entry_hi) suspect = true;
     if (t < tmax) return true;
     if (!(t == tmax)) return false;
     if (!QUADS) return !best_quad && pos < best_pos;
@@ -887,8 +926,18 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
     if (have) {  // a lane whose units ran out takes the far child it left behind, or hands in its result
       const uint32_t k = RTX_NODE_KIND((uint32_t)unit);
       if (i >= end || k == PROG_NODE_END || k == PROG_NODE_SYNC) {
-        if (sp == 0) { feed.commit(id, tmax, hit_kind, hit_ctx); have = false; }
-        else { sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu; }
+        if (sp == 0) {
+          if (suspect && !fixed_mode) {   // once more, in the reference's order
+            feed.note_redo();
+            feed.start(id, tmax, hit_kind, hit_ctx);
+            lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
+            cur = 0; i = begin; unit = prog[i]; single = root_single; end = 0xFFFFFFFFu;
+            suspect = false; fixed_mode = true; leaf_entry_hi = -RT_INF;
+            best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
+          } else {
+            feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
+          }
+        } else { sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu; }
       }
     }
     if (feed.more() && RT_WAVE_COUNT(!have) >= RT_NEAR_REFILL) {
@@ -898,6 +947,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         feed.start(id, tmax, hit_kind, hit_ctx);
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
         cur = 0; i = begin; unit = prog[i]; have = true; single = root_single; end = 0xFFFFFFFFu; sp = 0;
+        suspect = false; fixed_mode = false; leaf_entry_hi = -RT_INF;
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;   // a hit from before the section: position 0
       }
     }
@@ -952,12 +1002,16 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             // where the unit behind the box that is not taken is one more cache line to fetch (stress scene 79.3 -> 72.7).
             const uint64_t n0 = AHEAD ? prog[c0 + PROG_BOX_UNITS] : 0ull, n1 = (AHEAD && !single) ? prog[c1 + PROG_BOX_UNITS] : n0;
             double e0 = 0.0, e1 = 0.0;
-            const bool p0 = slab_hit_entry((const double*)(prog + c0 + 1), lr, tmin, tmax, e0);
-            const bool p1 = !single && slab_hit_entry((const double*)(prog + c1 + 1), lr, tmin, tmax, e1);
+            bool m0 = false, m1 = false;
+            const bool p0 = slab_hit_entry_margin((const double*)(prog + c0 + 1), lr, tmin, tmax, S.near_margin, e0, m0);
+            const bool p1 = !single && slab_hit_entry_margin((const double*)(prog + c1 + 1), lr, tmin, tmax, S.near_margin, e1, m1);
+            if (!fixed_mode && (m0 || (!single && m1))) suspect = true;   // a box culled by a hair
             if (p0 || p1) {
-              const bool first0 = p0 && (!p1 || e0 <= e1);            // equal entries: the reference's order
+              const bool first0 = p0 && (!p1 || fixed_mode || e0 <= e1);   // equal entries: the reference's order
               if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
               const uint32_t c = first0 ? c0 : c1;
+              const double e = first0 ? e0 : e1;
+              leaf_entry_hi = e + fabs(e) * S.near_margin;
               end = (uint32_t)((first0 ? unit : u1) >> 32);
               i = c + PROG_BOX_UNITS; unit = AHEAD ? (first0 ? n0 : n1) : prog[i]; single = false;
             } else if (sp > 0) {                                       // nothing here: on to the far child left behind

@@ -395,11 +395,14 @@ struct QueueFeed {
     else { tmax = RT_INF; kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0); ctx = 0; }
   }
   __device__ void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { ht[id] = tmax; hk[id] = kind; hc[id] = ctx; }
+  // A ray the nearer-child-first walk could not vouch for and walked again in the reference's order (statistics only).
+  uint32_t redos;
+  __device__ void note_redo() { redos += 1u; }
 };
 
 template <bool USE_LDS, bool TAIL, int NEAR = 0>   // NEAR: 1 = nearer child first over sphere leaves, 2 = quads in the leaves too
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t cap, WfCounters* c, WfQueue q, WfHits h,
-                                                    const uint32_t* __restrict__ defer_list) {
+                                                    const uint32_t* __restrict__ defer_list, unsigned long long* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
   const uint32_t n = TAIL ? c->n_defer : (S.fresh_in_main ? c->gen_slot : c->n_in);   // the head stream may leave the new paths out
   if (blockIdx.x * blockDim.x >= n) return;
@@ -415,12 +418,15 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   }
   QueueFeed feed;
   feed.qf = q.f; feed.cap = cap; feed.list = TAIL ? defer_list : nullptr;
-  feed.ht = h.t; feed.hk = h.kind_idx; feed.hc = h.ctx;
+  feed.ht = h.t; feed.hk = h.kind_idx; feed.hc = h.ctx; feed.redos = 0;
   feed.work = TAIL ? &c->work_tail : &c->work_head; feed.n = n; feed.n_waves = gridDim.x * (blockDim.x / 64u); feed.lane = threadIdx.x & 63u;
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
   if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
     walk_stream_near<NEAR == 2, USE_LDS>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
+    uint32_t r = feed.redos;   // statistics: one atomic per wave that had any
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+    if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&stats[5], (unsigned long long)r);
   } else {
     walk_stream(S, prog, TAIL ? S.tail_begin : S.world_begin, feed);
   }
@@ -834,7 +840,7 @@ struct rtx_context {
   int n_cus = 256;
   double wall_clock_khz = 100000.0;  // rate of wall_clock64()
   std::string error;
-  unsigned long long* d_counters = nullptr;  // paths, queue entries traversed, pdf_probes, roulette drops, dead entries among those traversed
+  unsigned long long* d_counters = nullptr;  // paths, queue entries traversed, pdf_probes, roulette drops, dead entries among those traversed, rays walked again in the reference's order
   double render_ms = 0.0, last_kernel_ms = 0.0, traverse_ms = 0.0, tail_ms = 0.0, head_ms = 0.0, shade_ms = 0.0;
   uint64_t launches = 0, traverse_launches = 0, tail_launches = 0, head_launches = 0, shade_launches = 0, iterations = 0;
   std::vector<TimedSpan> pending;  // timed spans not yet read back
@@ -1154,6 +1160,8 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   P.head_end = head_end;
   P.dev = sc->dev;
+  // testing knob: a wide margin sends many rays through the redo path (results must not change)
+  if (const char* e = getenv("RTX_WF_NEAR_MARGIN")) { const double v = atof(e); if (v >= 0.0 && v <= 1.0) P.dev.near_margin = v; }
   P.dev.head_end = head_end;
   // New camera paths are coherent (a wave holds one stratified sample of an 8 x 8 pixel tile): the per-ray walk with its
   // votes serves them better than the stream (final scene, camera rays only: 54.9 ms per 448 M rays through head and
@@ -1205,13 +1213,13 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
     TimedSpan sh;
     const bool timed_head = timed && span_begin(ctx, s, sh, 3);
     if (P.near_head_lds)
-      hipLaunchKernelGGL((k_wf_stream<true, false, 2>), tb, tt, P.head_bytes + P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<true, false, 2>), tb, tt, P.head_bytes + P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.near_head_global)
-      hipLaunchKernelGGL((k_wf_stream<false, false, 2>), tb, tt, P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<false, false, 2>), tb, tt, P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.head_lds)
-      hipLaunchKernelGGL((k_wf_stream<true, false, 0>), tb, tt, P.head_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<true, false, 0>), tb, tt, P.head_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else
-      hipLaunchKernelGGL((k_wf_stream<false, false, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<false, false, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     if (timed_head) span_end(ctx, s, sh);
   }
   if (!P.skip_main)
@@ -1221,17 +1229,17 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
     TimedSpan st;
     const bool timed_tail = timed && span_begin(ctx, s, st, 2);
     if (P.stream_tail && P.near_lds && P.near_quads)
-      hipLaunchKernelGGL((k_wf_stream<true, true, 2>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<true, true, 2>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.stream_tail && P.near_lds)
-      hipLaunchKernelGGL((k_wf_stream<true, true, 1>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<true, true, 1>), tb, tt, P.tail_bytes + P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.stream_tail && P.near_global && P.near_quads)
-      hipLaunchKernelGGL((k_wf_stream<false, true, 2>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<false, true, 2>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.stream_tail && P.near_global)
-      hipLaunchKernelGGL((k_wf_stream<false, true, 1>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<false, true, 1>), tb, tt, P.near_stack_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.stream_tail && P.tail_lds)
-      hipLaunchKernelGGL((k_wf_stream<true, true, 0>), tb, tt, P.tail_bytes, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<true, true, 0>), tb, tt, P.tail_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.stream_tail)
-      hipLaunchKernelGGL((k_wf_stream<false, true, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer);
+      hipLaunchKernelGGL((k_wf_stream<false, true, 0>), tb, tt, 0, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.tail_lds)
       hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
     else
@@ -1367,8 +1375,8 @@ static hipError_t call_end(rtx_context* ctx, hipStream_t stream) {
 // GPU the library runs on holds its own copy from the moment the code object is loaded until the process ends.  Host
 // code never uses the array's name as an address; noalloc_setup asks the runtime for the array's device address once
 // per device and everything after that goes through that pointer.
-#define RT_NOALLOC_COUNTER_BYTES 2048u
-#define RT_NOALLOC_PER_PATH (2u * (10u * 8u + 3u * 4u) + 8u + 4u + 4u + 16u + 4u)   // two queues, hit (t, kind, ctx, uv), defer
+#define RT_NOALLOC_COUNTER_BYTES 4096u
+#define RT_NOALLOC_PER_PATH (2u * (10u * 8u + 3u * 4u) + 8u + 4u + 4u + 16u + 4u)   // two queues, hit (t, kind, ctx, uv), defer list
 #define RT_NOALLOC_BYTES (RT_NOALLOC_COUNTER_BYTES + (size_t)RTX_NOALLOC_MAX_PATHS * RT_NOALLOC_PER_PATH)
 static_assert(sizeof(WfCounters) <= RT_NOALLOC_COUNTER_BYTES, "counters outgrew their part of the scratch array");
 static_assert(RTX_NOALLOC_MAX_PATHS % 256 == 0, "queue capacity must be a multiple of 256");
@@ -1416,8 +1424,8 @@ rtx_status rtx_context_create(int n_devices, const int* device_ids, rtx_context*
   rtx_context* ctx = new rtx_context();
   ctx->device = dev;
   hipDeviceProp_t prop;
-  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 5 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(ctx->d_counters, 0, 5 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+  if (hipSetDevice(dev) != hipSuccess || hipMalloc(&ctx->d_counters, 6 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(ctx->d_counters, 0, 6 * sizeof(unsigned long long)) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     delete ctx;
     return fail(nullptr, RTX_ERR_HIP, "rtx_context_create: device initialisation failed");
   }
@@ -1470,7 +1478,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN;
   sc->n_general_media = prog.n_general_media;
   sc->nothing_behind_head = false;
   if (prog.head_end && !prog.tail_begin && d->n_media == 0) {
@@ -1672,9 +1680,9 @@ rtx_status rtx_get_stats(rtx_context* ctx, rtx_stats* out) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  unsigned long long c[5] = {0, 0, 0, 0, 0};
+  unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
   HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-  out->paths = c[0]; out->segments = c[1] - c[4]; out->pdf_probes = c[2]; out->roulette_drops = c[3];  // c[4]: dead entries the traversal walked
+  out->paths = c[0]; out->segments = c[1] - c[4]; out->pdf_probes = c[2]; out->roulette_drops = c[3]; out->order_redos = c[5];  // c[4]: dead entries the traversal walked
   out->render_ms = ctx->render_ms; out->launches = ctx->launches; out->last_kernel_ms = ctx->last_kernel_ms;
   out->traverse_ms = ctx->traverse_ms; out->traverse_launches = ctx->traverse_launches;
   out->tail_ms = ctx->tail_ms; out->tail_launches = ctx->tail_launches;
@@ -1688,7 +1696,7 @@ rtx_status rtx_reset_stats(rtx_context* ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipDeviceSynchronize());
   drain_events(ctx);
-  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 5 * sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, 6 * sizeof(unsigned long long)));
   ctx->render_ms = 0.0; ctx->launches = 0; ctx->last_kernel_ms = 0.0; ctx->traverse_ms = 0.0; ctx->traverse_launches = 0; ctx->tail_ms = 0.0; ctx->tail_launches = 0; ctx->head_ms = 0.0; ctx->head_launches = 0; ctx->shade_ms = 0.0; ctx->shade_launches = 0; ctx->iterations = 0;
   return RTX_OK;
 }

@@ -71,7 +71,10 @@ struct HostFeed {
     else { tmax = RT_INF; kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0); ctx = 0; }
   }
   void commit(uint32_t id, double tmax, uint32_t kind, uint32_t ctx) const { hits[id].t = tmax; hits[id].kind_idx = kind; hits[id].ctx = ctx; }
+  int* redos;                     // rays the nearer-child-first walk walked a second time, in the fixed order
+  void note_redo() const { if (redos) *redos += 1; }
 };
+static int g_redos = 0;
 
 int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                          uint32_t* mat_id, uint8_t* front) {
@@ -81,16 +84,18 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   if (!S.head_end && !S.tail_begin) return -1;
   std::vector<Hit> hits(n);
   std::vector<uint32_t> deferred;
-  int streamed = 0, near_walks = 0;
+  int streamed = 0, near_walks = 0, redos = 0;
   if (S.head_end) {
-    HostFeed feed{rays, nullptr, n, 0, hits.data(), false};
+    HostFeed feed{rays, nullptr, n, 0, hits.data(), false, &redos};
     std::vector<uint32_t> stk(S.head_near_depth + 1u);
-    if (g_near == 2 && S.head_near_depth > 0) { walk_stream_near<true, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1; }
+    if (g_near == 2 && S.head_near_depth > 0) {
+      walk_stream_near<true, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1;
+    }
     else walk_stream(S, S.prog, S.world_begin, feed);
     streamed += (int)n;
   }
   for (size_t i = 0; i < n; ++i) {
-    HostFeed one{rays, nullptr, n, 0, hits.data(), false};
+    HostFeed one{rays, nullptr, n, 0, hits.data(), false, nullptr};
     const RayRegs rs = one.ray((uint32_t)i);
     Hit h;
     const double t0 = S.head_end ? hits[i].t : RT_INF;
@@ -101,15 +106,18 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
     if (d) deferred.push_back((uint32_t)i);
   }
   if (S.tail_begin) {
-    HostFeed feed{rays, deferred.data(), deferred.size(), 0, hits.data(), true};
+    HostFeed feed{rays, deferred.data(), deferred.size(), 0, hits.data(), true, &redos};
     std::vector<uint32_t> stk(S.tail_near_depth + 1u);
-    if (g_near >= 1 && S.tail_near_depth > 0 && S.tail_near_quads) { walk_stream_near<true, false>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
-    else if (g_near >= 1 && S.tail_near_depth > 0) { walk_stream_near<false, true>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false); near_walks += 1; }
+    if (g_near >= 1 && S.tail_near_depth > 0) {
+      if (S.tail_near_quads) walk_stream_near<true, false>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false);
+      else walk_stream_near<false, true>(S, S.prog, S.tail_begin, feed, stk.data(), 1u, false);
+      near_walks += 1;
+    }
     else walk_stream(S, S.prog, S.tail_begin, feed);
     streamed += (int)deferred.size();
   }
   for (size_t i = 0; i < n; ++i) {
-    HostFeed one{rays, nullptr, n, 0, hits.data(), false};
+    HostFeed one{rays, nullptr, n, 0, hits.data(), false, nullptr};
     const Ray ray = one.ray((uint32_t)i).r;
     const Hit h = hits[i];
     const bool any = hit_any(h);
@@ -121,12 +129,13 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
     if (mat_id) mat_id[i] = any ? sf.mat : 0xFFFFFFFFu;
     if (front) front[i] = any ? (sf.front ? 1 : 0) : 0;
   }
-  g_near_walks = near_walks;
+  g_near_walks = near_walks; g_redos = redos;
   return streamed;
 }
 
 void sim_set_near(int mode) { g_near = mode; }
-int sim_near_walks(void) { return g_near_walks; }   // sections the last staged walk took nearer child first
+int sim_near_walks(void) { return g_near_walks; }
+int sim_order_redos(void) { return g_redos; }          // rays of the last staged walk that went through the fixed order again   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }

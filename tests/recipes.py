@@ -181,3 +181,31 @@ def texture_probe(g):
     cam = dict(aspect_ratio=1.25, image_width=160, samples_per_pixel=4, max_depth=1, background=(0.1, 0.2, 0.3),
                vfov=60.0, lookfrom=(0.3, 1.5, 14.0), lookat=(0.0, 1.0, 0.0))
     return g.list(prims), cam, texs
+
+
+def ties_on_box_boundaries(g):
+    """Hits that lie ON the boundary of their own bounding box and tie with another hit: pairs of spheres that touch at a
+    point where both touch their boxes (centres (0, y, z) radius 1 and (1, y, z) radius 2 meet at x = -1), hit by rays
+    along the x axis, so that the box entry, and both hit parameters, are the same number to the last bit.  Which sphere
+    the reference reports depends on the upper bound its left-to-right walk has reached when it tests the second box
+    (bvh.rs:94-102: `t <= entry` culls it); small off-axis spheres vary the shape of the tree from cell to cell, so that
+    a nearer-child-first walk visits some pairs in the other order.  The spheres form the last top-level BVH (the
+    deferred section of the wavefront pipeline)."""
+    rng = np.random.default_rng(109)
+    mats = _materials(g)
+    spheres, rays = [], []
+    for i in range(10):
+        for j in range(10):
+            y, z = 10.0 * i, 10.0 * j
+            cell = [g.sphere((0.0, y, z), 1.0, mats[0]), g.sphere((1.0, y, z), 2.0, mats[1])]
+            for _ in range(int(rng.integers(0, 3))):                       # decoys the axis rays miss
+                cell.append(g.sphere((float(rng.integers(-4, 6)), y + float(rng.choice([-3.0, 3.0])), z + float(rng.integers(-1, 2))), 0.5, mats[2]))
+            for k in rng.permutation(len(cell)):
+                spheres.append(cell[int(k)])
+            for ox, dx in ((-5.0, 1.0), (-9.0, 2.0), (-3.0, 0.5), (-5.0, 4.0)):
+                rays.append([ox, y, z, dx, 0.0, 0.0, 0.0])
+            rays.append([8.0, y, z, -1.0, 0.0, 0.0, 0.0])                   # from the other side: no tie
+    order = rng.permutation(len(spheres))
+    world = g.list([g.quad((-50, -60, -50), (200, 0, 0), (0, 0, 200), mats[3]), g.bvh(g.list([spheres[int(k)] for k in order]))])
+    rays = np.array(rays, dtype=np.float64)
+    return world, None, np.concatenate([rays, _rays_towards(rng, 3000, np.array([0.0, 45.0, 45.0]), 60.0, 200.0)])

@@ -106,6 +106,27 @@ def test_nearer_child_first_finds_the_same_hits(name):
         assert sum((q in ids) + (q + 1 in ids) for q in quads) == sum((q in ids) or (q + 1 in ids) for q in quads) >= 12
 
 
+def test_nearer_child_first_hands_back_what_depends_on_the_order():
+    """The one case in which the visiting order can change a closest hit: a hit on the boundary of its own bounding box
+    that ties with another (recipes.ties_on_box_boundaries is made of them).  The nearer-child-first walk notices such
+    rays (a candidate hit not behind its box's entry, or a box culled by a hair) and hands them back; they are walked
+    again in the reference's order, so the staged walk still equals the undivided fixed-order walk and the oracle, bit
+    for bit.  (With the watch compiled out, 79 of these rays report the other sphere of their pair.)"""
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, _, rays = recipes.ties_on_box_boundaries(go)
+    wp, lp, _ = recipes.ties_on_box_boundaries(gp)
+    d = rt.flatten(gp, wp, lp)
+    whole = H.hostsim_first_hit(d, rays)
+    H.assert_aov_equal(H.oracle_first_hit(go, wo, rays), whole, "boundary ties, fixed order")
+    staged, streamed = H.hostsim_first_hit_staged(d, rays, near=1)
+    assert H.hostsim_lib().sim_near_walks() == 1
+    redos = H.hostsim_lib().sim_order_redos()
+    H.assert_aov_equal(whole, staged, "boundary ties, nearer child first")
+    assert 300 <= redos < 1000, redos                     # the axis rays of the 100 cells, not the random ones
+    tie = np.isclose(whole["t"][:500:5], 4.0) & (rays[:500:5, 3] == 1.0)
+    assert tie.sum() == 100                                # the pairs do tie where the recipe says
+
+
 def test_final_scene_bvh_shape():
     """400 leaves -> 511 nodes, 1000 leaves -> 1023 nodes (f(1)=f(2)=1, f(n)=1+f(n/2)+f(n-n/2)), bvh.rs:26-71."""
     g = rt.Graph()
