@@ -47,6 +47,8 @@ struct CompiledProgram {
   uint32_t head_near_depth = 0;    // > 0: so is the head section under its root box
   uint32_t tail_near_quads = 0;    // the deferred section's leaves hold quads (it needs the walk's quad classes)
   uint32_t defer_pos = 0;          // unit index of the DEFER unit
+  uint32_t head_top_begin = 0, head_top_nodes = 0;   // Scene::head_top_*: the first levels of the head section's box tree
+  uint32_t head_top_max_levels = 10;                 // 1023 records = 57 KB of LDS next to the walk's stacks
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
   // a medium boundary).
@@ -98,6 +100,7 @@ struct CompiledProgram {
     }
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
+    build_head_top();
   }
 
   // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
@@ -109,6 +112,7 @@ struct CompiledProgram {
     S.media = media.data();
     S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
     S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr; S.near_margin = RT_NEAR_MARGIN;
+    S.head_top_begin = head_top_begin; S.head_top_nodes = head_top_nodes;
     return S;
   }
 
@@ -149,6 +153,43 @@ struct CompiledProgram {
       if (k != PROG_NODE_SPHERE_S && k != PROG_NODE_NOP && !(quads && (k == PROG_NODE_QUAD_AA || k == PROG_NODE_BOX6 || k == RTX_NODE_QUAD))) return -1;
     }
     return 0;
+  }
+  // The first levels of the head section's box tree in heap order, appended to the image: as many whole levels (at most
+  // head_top_max_levels) as consist of boxes with two box children each.  Only for a head section that has the
+  // nearer-child-first shape and is too large to be staged whole (a section that fits LDS is read from there anyway).
+  void build_head_top() {
+    head_top_begin = 0; head_top_nodes = 0;
+    if (!head_end || head_near_depth == 0 || (size_t)head_end * 8 <= 160u * 1024u) return;
+    auto is_box = [&](uint32_t p) { return p < head_end && RTX_NODE_KIND((uint32_t)units[p]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)units[p]) != PROG_GUARD_IDX; };
+    std::vector<uint32_t> pos{world_begin};
+    if (!is_box(world_begin)) return;
+    uint32_t levels = 1;
+    for (size_t first = 0; levels < head_top_max_levels; ++levels) {   // level by level: every node needs two box children
+      const size_t last = pos.size();
+      std::vector<uint32_t> next;
+      bool whole = true;
+      for (size_t k = first; k < last && whole; ++k) {
+        const uint32_t c0 = pos[k] + PROG_BOX_UNITS;
+        if (!is_box(c0)) { whole = false; break; }
+        const uint32_t c1 = (uint32_t)(units[c0] >> 32);
+        if (!is_box(c1)) { whole = false; break; }
+        next.push_back(c0); next.push_back(c1);
+      }
+      if (!whole) break;
+      first = last;
+      pos.insert(pos.end(), next.begin(), next.end());
+    }
+    if (levels < 3) return;
+    head_top_nodes = (1u << levels) - 1u;
+    pos.resize(head_top_nodes);
+    head_top_begin = (uint32_t)units.size();
+    std::vector<uint64_t> table;
+    table.reserve((size_t)head_top_nodes * PROG_BOX_UNITS);
+    for (uint32_t h = 0; h < head_top_nodes; ++h) table.insert(table.end(), units.begin() + pos[h], units.begin() + pos[h] + PROG_BOX_UNITS);
+    units.insert(units.end(), table.begin(), table.end());
+    if (units.size() & 1u) units.push_back(nop());
+    for (uint32_t h = 0; h < head_top_nodes; h += 2) units.push_back((uint64_t)pos[h] | ((uint64_t)(h + 1 < head_top_nodes ? pos[h + 1] : 0u) << 32));
+    if (units.size() & 1u) units.push_back(nop());
   }
   static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }
   static uint64_t bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }

@@ -70,6 +70,10 @@ struct Scene : rtx_scene_desc {
   const rtx_quad* light_quads;
   const rtx_sphere* light_spheres;
   double near_margin;   // relative margin of the nearer-child-first walk's order-dependence watch (RT_NEAR_MARGIN by default)
+  // Top of the head section's box tree, for a walk of a program that stays in global memory: copies of the box records
+  // of its first levels in heap order (root 0, children of h at 2h+1 and 2h+2), 7 units each, at unit head_top_begin of
+  // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none.
+  uint32_t head_top_begin, head_top_nodes;
 };
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
@@ -891,8 +895,15 @@ RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, doubl
 #ifndef RT_NEAR_LEAF_BIAS_FAR_DEN
 #define RT_NEAR_LEAF_BIAS_FAR_DEN 1
 #endif
-template <bool QUADS, bool AHEAD, class Feed>
-RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single) {
+//   TOP: the first levels of the tree are also held in a table in heap order (top: 7-unit box records, top_pos: their
+//   unit positions, top_n of them; Scene::head_top_*), which the caller keeps in fast memory while the program itself
+//   stays in global memory: a lane then carries the heap index of the box it stands on (hx; HX_NONE below the table)
+//   and reads the bounds and headers of tabled boxes from the table.  The positions, and so the walk, are unchanged.
+template <bool QUADS, bool AHEAD, bool TOP = false, class Feed>
+RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, bool root_single,
+                            const uint64_t* top = nullptr, const uint32_t* top_pos = nullptr, uint32_t top_n = 0) {
+  const uint32_t HX_NONE = 0xFFFFFFFFu;
+  uint32_t hx = HX_NONE;   // TOP: heap index of the box at i (of the left one of a pair); its sibling is hx + 1
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_QUAD = 4, CL_BOX6 = 7, CL_BOX = 8, CL_DONE = 10 };
   const int bias = AHEAD ? RT_NEAR_LEAF_BIAS : RT_NEAR_LEAF_BIAS_FAR, bias_den = AHEAD ? 1 : RT_NEAR_LEAF_BIAS_FAR_DEN;
   const double tmin = 0.001;
@@ -932,12 +943,19 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             feed.start(id, tmax, hit_kind, hit_ctx);
             lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
             cur = 0; i = begin; unit = prog[i]; single = root_single; end = 0xFFFFFFFFu;
+            hx = (TOP && top_n) ? 0u : HX_NONE;
             suspect = false; fixed_mode = true; leaf_entry_hi = -RT_INF;
             best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
           } else {
             feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
           }
-        } else { sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu; }
+        } else {
+          sp -= 1;
+          const uint32_t e = stk[sp * stk_stride];
+          if (TOP && (e & 0x80000000u)) { hx = e & 0x7FFFFFFFu; i = top_pos[hx]; unit = top[hx * PROG_BOX_UNITS]; }
+          else { i = e; unit = prog[i]; hx = HX_NONE; }
+          single = true; end = 0xFFFFFFFFu;
+        }
       }
     }
     if (feed.more() && RT_WAVE_COUNT(!have) >= RT_NEAR_REFILL) {
@@ -947,6 +965,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         feed.start(id, tmax, hit_kind, hit_ctx);
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
         cur = 0; i = begin; unit = prog[i]; have = true; single = root_single; end = 0xFFFFFFFFu; sp = 0;
+        hx = (TOP && top_n) ? 0u : HX_NONE;
         suspect = false; fixed_mode = false; leaf_entry_hi = -RT_INF;
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;   // a hit from before the section: position 0
       }
@@ -995,7 +1014,11 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             i = pass ? c0 + PROG_BOX_UNITS : c1; unit = prog[i < end ? i : begin];
           } else {
             // the box at i, and unless `single` its sibling (the two children of the box this lane came through)
-            const uint64_t u1 = single ? unit : prog[c1];
+            // TOP: which of the two boxes are in the table (a pair is, or is not, as a whole: the table holds whole levels)
+            const bool t0 = TOP && hx < top_n, t1 = TOP && !single && t0;
+            const uint64_t* r0 = t0 ? top + hx * PROG_BOX_UNITS : prog + c0;
+            const uint64_t* r1 = t1 ? top + (hx + 1u) * PROG_BOX_UNITS : prog + c1;
+            const uint64_t u1 = single ? unit : r1[0];
             // AHEAD: the units behind both boxes are read together with the bounds; the walk goes on with one of them
             // (the image is padded past its END).  It pays a little for a program in LDS (one dependent read less per
             // level: final scene 2257-2265 -> 2268-2289 Msamples/s over repeated runs), not for one in global memory,
@@ -1003,19 +1026,33 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             const uint64_t n0 = AHEAD ? prog[c0 + PROG_BOX_UNITS] : 0ull, n1 = (AHEAD && !single) ? prog[c1 + PROG_BOX_UNITS] : n0;
             double e0 = 0.0, e1 = 0.0;
             bool m0 = false, m1 = false;
-            const bool p0 = slab_hit_entry_margin((const double*)(prog + c0 + 1), lr, tmin, tmax, S.near_margin, e0, m0);
-            const bool p1 = !single && slab_hit_entry_margin((const double*)(prog + c1 + 1), lr, tmin, tmax, S.near_margin, e1, m1);
+            const bool p0 = slab_hit_entry_margin((const double*)(r0 + 1), lr, tmin, tmax, S.near_margin, e0, m0);
+            const bool p1 = !single && slab_hit_entry_margin((const double*)(r1 + 1), lr, tmin, tmax, S.near_margin, e1, m1);
             if (!fixed_mode && (m0 || (!single && m1))) suspect = true;   // a box culled by a hair
             if (p0 || p1) {
               const bool first0 = p0 && (!p1 || fixed_mode || e0 <= e1);   // equal entries: the reference's order
-              if (p0 && p1) { stk[sp * stk_stride] = first0 ? c1 : c0; sp += 1; }
+              if (p0 && p1) {   // the far child waits on the stack: by heap index while it is in the table, else by position
+                const uint32_t far_pos = first0 ? c1 : c0, far_hx = first0 ? hx + 1u : hx;
+                stk[sp * stk_stride] = t1 ? (0x80000000u | far_hx) : far_pos; sp += 1;
+              }
               const uint32_t c = first0 ? c0 : c1;
               const double e = first0 ? e0 : e1;
               leaf_entry_hi = e + fabs(e) * S.near_margin;
               end = (uint32_t)((first0 ? unit : u1) >> 32);
-              i = c + PROG_BOX_UNITS; unit = AHEAD ? (first0 ? n0 : n1) : prog[i]; single = false;
+              i = c + PROG_BOX_UNITS; single = false;
+              if (TOP) {   // the children of the box just entered: heap 2h+1 and 2h+2, in the table or not together
+                const uint32_t hc = t0 ? (first0 ? hx : hx + 1u) : HX_NONE;
+                hx = (hc != HX_NONE && 2u * hc + 2u < top_n) ? 2u * hc + 1u : HX_NONE;
+                unit = hx != HX_NONE ? top[hx * PROG_BOX_UNITS] : prog[i];
+              } else {
+                unit = AHEAD ? (first0 ? n0 : n1) : prog[i];
+              }
             } else if (sp > 0) {                                       // nothing here: on to the far child left behind
-              sp -= 1; i = stk[sp * stk_stride]; unit = prog[i]; single = true; end = 0xFFFFFFFFu;
+              sp -= 1;
+              const uint32_t e = stk[sp * stk_stride];
+              if (TOP && (e & 0x80000000u)) { hx = e & 0x7FFFFFFFu; i = top_pos[hx]; unit = top[hx * PROG_BOX_UNITS]; }
+              else { i = e; unit = prog[i]; hx = HX_NONE; }
+              single = true; end = 0xFFFFFFFFu;
             } else {
               i = 0xFFFFFFFFu - 1u; end = 0u;                          // the section is done: the top of the loop hands in
             }

@@ -423,7 +423,17 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
   if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
-    walk_stream_near<NEAR == 2, USE_LDS>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
+    if (!USE_LDS && !TAIL && NEAR == 2 && S.head_top_nodes) {
+      // a head section walked from global memory: the first levels of its tree (heap order, with their unit positions)
+      // are staged behind the stacks, so that the walk leaves LDS only below them
+      uint64_t* top = lds_prog + (size_t)S.head_near_depth * (blockDim.x / 2u);
+      const uint32_t box_units = (S.head_top_nodes * PROG_BOX_UNITS + 1u) & ~1u, all_units = S.n_units - S.head_top_begin;
+      for (uint32_t k = threadIdx.x; k < all_units; k += blockDim.x) top[k] = S.prog[S.head_top_begin + k];
+      __syncthreads();
+      walk_stream_near<true, false, true>(S, prog, S.world_begin, feed, stk, blockDim.x, true, top, (const uint32_t*)(top + box_units), S.head_top_nodes);
+    } else {
+      walk_stream_near<NEAR == 2, USE_LDS>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
+    }
     uint32_t r = feed.redos;   // statistics: one atomic per wave that had any
     for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
     if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&stats[5], (unsigned long long)r);
@@ -1109,7 +1119,7 @@ struct WfPlan {
   Scene dev;                 // the scene as the traversal kernels see it (head_end, fresh_in_main set for this plan)
   uint32_t cap = 0;
   uint32_t head_end = 0, tail_begin = 0;
-  size_t head_bytes = 0, tail_bytes = 0, main_bytes = 0, defer_bytes = 0, near_stack_bytes = 0, near_head_stack = 0;
+  size_t head_bytes = 0, tail_bytes = 0, main_bytes = 0, defer_bytes = 0, near_stack_bytes = 0, near_head_stack = 0, head_top_bytes = 0;
   bool head_lds = false, tail_lds = false, main_lds = false, stream_tail = false;
   bool near_lds = false, near_global = false, near_quads = false, near_head_lds = false, near_head_global = false;
   bool skip_main = false;
@@ -1157,9 +1167,13 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
   P.near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
   P.near_head_lds = near_head_ok && P.head_lds && P.head_bytes + P.near_head_stack <= kLdsBudget;
   P.near_head_global = near_head_ok && !P.head_lds && P.near_head_stack <= kLdsBudget;
+  P.head_top_bytes = (size_t)(sc->dev.head_top_nodes ? sc->dev.n_units - sc->dev.head_top_begin : 0u) * 8;
+  const char* top_env = getenv("RTX_WF_TOP");   // 0: walk the whole head section from global memory
+  if (!P.near_head_global || P.near_head_stack + P.head_top_bytes > kLdsBudget || (top_env && atoi(top_env) == 0)) P.head_top_bytes = 0;
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   P.head_end = head_end;
   P.dev = sc->dev;
+  if (P.head_top_bytes == 0) P.dev.head_top_nodes = 0;
   // testing knob: a wide margin sends many rays through the redo path (results must not change)
   if (const char* e = getenv("RTX_WF_NEAR_MARGIN")) { const double v = atof(e); if (v >= 0.0 && v <= 1.0) P.dev.near_margin = v; }
   P.dev.head_end = head_end;
@@ -1215,7 +1229,7 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
     if (P.near_head_lds)
       hipLaunchKernelGGL((k_wf_stream<true, false, 2>), tb, tt, P.head_bytes + P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.near_head_global)
-      hipLaunchKernelGGL((k_wf_stream<false, false, 2>), tb, tt, P.near_head_stack, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
+      hipLaunchKernelGGL((k_wf_stream<false, false, 2>), tb, tt, P.near_head_stack + P.head_top_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else if (P.head_lds)
       hipLaunchKernelGGL((k_wf_stream<true, false, 0>), tb, tt, P.head_bytes, s, dev, cap, B.c, qin, B.hits, B.defer, ctx->d_counters);
     else
@@ -1478,7 +1492,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN; sc->dev.head_top_begin = prog.head_top_begin; sc->dev.head_top_nodes = prog.head_top_nodes;
   sc->n_general_media = prog.n_general_media;
   sc->nothing_behind_head = false;
   if (prog.head_end && !prog.tail_begin && d->n_media == 0) {

@@ -18,7 +18,7 @@ static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 using namespace rt;
 
 static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true;  // compile options under test
-static int g_near_walks = 0;
+static int g_near_walks = 0, g_top_walks = 0;
 static int g_near = 0;  // staged walk: 1 = the deferred section nearer child first, 2 = the head section too
 
 extern "C" {
@@ -89,7 +89,15 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
     HostFeed feed{rays, nullptr, n, 0, hits.data(), false, &redos};
     std::vector<uint32_t> stk(S.head_near_depth + 1u);
     if (g_near == 2 && S.head_near_depth > 0) {
-      walk_stream_near<true, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true); near_walks += 1;
+      if (S.head_top_nodes) {   // as the GPU walks a head section that stays in global memory: first levels from the table
+        const uint64_t* top = S.prog + S.head_top_begin;
+        const uint32_t box_units = (S.head_top_nodes * PROG_BOX_UNITS + 1u) & ~1u;
+        walk_stream_near<true, false, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true, top, (const uint32_t*)(top + box_units), S.head_top_nodes);
+        g_top_walks += 1;
+      } else {
+        walk_stream_near<true, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true);
+      }
+      near_walks += 1;
     }
     else walk_stream(S, S.prog, S.world_begin, feed);
     streamed += (int)n;
@@ -135,6 +143,7 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
 
 void sim_set_near(int mode) { g_near = mode; }
 int sim_near_walks(void) { return g_near_walks; }
+int sim_top_walks(void) { return g_top_walks; }        // head sections walked with their first levels from the heap-ordered table, so far
 int sim_order_redos(void) { return g_redos; }          // rays of the last staged walk that went through the fixed order again   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }

@@ -94,8 +94,11 @@ def test_nearer_child_first_finds_the_same_hits(name):
     d = rt.flatten(gp, wp, lp)
     whole = H.hostsim_first_hit(d, rays)
     for near, walks in ((1, 0 if name == "stress" else 1), (2, 1 if name == "stress" else 2)):
+        tops = H.hostsim_lib().sim_top_walks()
         staged, streamed = H.hostsim_first_hit_staged(d, rays, near=near)
         assert H.hostsim_lib().sim_near_walks() == walks
+        # the stress scene's BVH does not fit LDS: its first levels are read from the heap-ordered table (same walk)
+        assert H.hostsim_lib().sim_top_walks() - tops == (1 if name == "stress" and near == 2 else 0)
         H.assert_aov_equal(whole, staged, f"{name} near={near}")
         assert streamed >= len(rays)
     hit = np.isfinite(whole["t"])
