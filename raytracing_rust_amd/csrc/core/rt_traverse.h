@@ -823,7 +823,9 @@ RT_HD bool slab_hit_entry(const double* b, const LRay& r, double tmin, double tm
 #ifndef RT_NEAR_MARGIN
 #define RT_NEAR_MARGIN 1e-9
 #endif
-RT_HD bool slab_hit_entry_margin(const double* b, const LRay& r, double tmin, double tmax, double margin, double& entry, bool& close_call) {
+RT_HD bool slab_hit_entry_margin(const double* b, const LRay& r, double tmin, double tmax, double tmax_hi, double& entry, bool& close_call) {
+  // tmax_hi = tmax plus the margin, kept by the caller.  The far planes are folded into the LARGER bound first; the
+  // decision for tmax itself then takes one more min (min is exact, so this is slab_hit's value: tmax <= tmax_hi).
   const uint32_t nx = r.inv.x >= 0.0 ? 0u : 3u, ny = r.inv.y >= 0.0 ? 0u : 3u, nz = r.inv.z >= 0.0 ? 0u : 3u;
   const double bnx = b[nx], bfx = b[3u - nx], bny = b[1u + ny], bfy = b[4u - ny], bnz = b[2u + nz], bfz = b[5u - nz];
   double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
@@ -834,14 +836,12 @@ RT_HD bool slab_hit_entry_margin(const double* b, const LRay& r, double tmin, do
     if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
     if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
   }
-  const double tmax_in = tmax;
-  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
-  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
-  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
+  tmin = rt_max(tmin, nrx); tmax_hi = rt_min(tmax_hi, frx);
+  tmin = rt_max(tmin, nry); tmax_hi = rt_min(tmax_hi, fry);
+  tmin = rt_max(tmin, nrz); tmax_hi = rt_min(tmax_hi, frz);
   entry = tmin;
-  const bool pass = !(tmax <= tmin);
-  // failed because of the upper bound alone (the far planes lie behind the entry), and by less than the margin
-  close_call = !pass && tmax == tmax_in && tmax_in + tmax_in * margin > tmin;
+  const bool pass = !(rt_min(tmax_hi, tmax) <= tmin);
+  close_call = !pass && !(tmax_hi <= tmin);   // fails with tmax, would pass with the margin added
   return pass;
 }
 // Sphere::hit for a static sphere with an inclusive upper bound: a root equal to tmax is reported, so that the caller
@@ -917,7 +917,8 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   // tested together with it, waits on the stack and is tested again with the bound the left subtree leaves behind,
   // which is when and how bvh.rs:94-102 tests it).
   bool suspect = false, fixed_mode = false;
-  double leaf_entry_hi = -RT_INF;   // entry of the last box this lane went through, plus the margin
+  double leaf_entry = -RT_INF;      // entry of the last box this lane went through
+  double tmax_hi = RT_INF;          // tmax plus the margin
   uint32_t id = 0, i = begin, end = 0xFFFFFFFFu, sp = 0, cur = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
   uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
   double tmax = RT_INF;
@@ -926,7 +927,9 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
   // a hit at t from the primitive at program position pos: does it replace the best one so far?
   auto wins = [&](double t, uint32_t pos, bool quad) {
-    if (!fixed_mode && t <= leaf_entry_hi) suspect = true;
+#if !defined(RT_WATCH_NO_LEAF)
+    if (!fixed_mode && t <= leaf_entry + fabs(leaf_entry) * S.near_margin) suspect = true;
+#endif
     if (t < tmax) return true;
     if (!(t == tmax)) return false;
     if (!QUADS) return !best_quad && pos < best_pos;
@@ -940,11 +943,11 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
         if (sp == 0) {
           if (suspect && !fixed_mode) {   // once more, in the reference's order
             feed.note_redo();
-            feed.start(id, tmax, hit_kind, hit_ctx);
+            feed.start(id, tmax, hit_kind, hit_ctx); tmax_hi = tmax + tmax * S.near_margin;
             lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
             cur = 0; i = begin; unit = prog[i]; single = root_single; end = 0xFFFFFFFFu;
             hx = (TOP && top_n) ? 0u : HX_NONE;
-            suspect = false; fixed_mode = true; leaf_entry_hi = -RT_INF;
+            suspect = false; fixed_mode = true; leaf_entry = -RT_INF;
             best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
           } else {
             feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
@@ -962,11 +965,11 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
       uint32_t nid = 0;
       if (feed.take(!have, nid)) {
         id = nid; rs = feed.ray(id);
-        feed.start(id, tmax, hit_kind, hit_ctx);
+        feed.start(id, tmax, hit_kind, hit_ctx); tmax_hi = tmax + tmax * S.near_margin;
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
         cur = 0; i = begin; unit = prog[i]; have = true; single = root_single; end = 0xFFFFFFFFu; sp = 0;
         hx = (TOP && top_n) ? 0u : HX_NONE;
-        suspect = false; fixed_mode = false; leaf_entry_hi = -RT_INF;
+        suspect = false; fixed_mode = false; leaf_entry = -RT_INF;
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;   // a hit from before the section: position 0
       }
     }
@@ -1026,9 +1029,11 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             const uint64_t n0 = AHEAD ? prog[c0 + PROG_BOX_UNITS] : 0ull, n1 = (AHEAD && !single) ? prog[c1 + PROG_BOX_UNITS] : n0;
             double e0 = 0.0, e1 = 0.0;
             bool m0 = false, m1 = false;
-            const bool p0 = slab_hit_entry_margin((const double*)(r0 + 1), lr, tmin, tmax, S.near_margin, e0, m0);
-            const bool p1 = !single && slab_hit_entry_margin((const double*)(r1 + 1), lr, tmin, tmax, S.near_margin, e1, m1);
+            const bool p0 = slab_hit_entry_margin((const double*)(r0 + 1), lr, tmin, tmax, tmax_hi, e0, m0);
+            const bool p1 = !single && slab_hit_entry_margin((const double*)(r1 + 1), lr, tmin, tmax, tmax_hi, e1, m1);
+#if !defined(RT_WATCH_NO_CLOSE)
             if (!fixed_mode && (m0 || (!single && m1))) suspect = true;   // a box culled by a hair
+#endif
             if (p0 || p1) {
               const bool first0 = p0 && (!p1 || fixed_mode || e0 <= e1);   // equal entries: the reference's order
               if (p0 && p1) {   // the far child waits on the stack: by heap index while it is in the table, else by position
@@ -1037,7 +1042,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
               }
               const uint32_t c = first0 ? c0 : c1;
               const double e = first0 ? e0 : e1;
-              leaf_entry_hi = e + fabs(e) * S.near_margin;
+              leaf_entry = e;
               end = (uint32_t)((first0 ? unit : u1) >> 32);
               i = c + PROG_BOX_UNITS; single = false;
               if (TOP) {   // the children of the box just entered: heap 2h+1 and 2h+2, in the table or not together
@@ -1080,7 +1085,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
           const DSphere sph = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
           const uint32_t pos = (i << 6) + k + 1u;                      // program order of this sphere (0 = before the section)
           if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, false)) {
-            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; best_pos = pos; best_quad = false;
+            tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; best_pos = pos; best_quad = false;
           }
         }
         RT_TRACE_STEP(32u + (uint32_t)CL_SPHERE_S);
@@ -1094,7 +1099,7 @@ RT_UNROLL
           double t;
           const uint32_t pos = (i << 6) + (uint32_t)f + 1u;
           if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
-            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; best_pos = pos; best_quad = true;
+            tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; best_pos = pos; best_quad = true;
           }
         }
         RT_TRACE_STEP(32u + (uint32_t)CL_BOX6);
@@ -1109,7 +1114,7 @@ RT_UNROLL
           double t;
           const uint32_t pos = (i << 6) + k + 1u;
           if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
-            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
+            tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
           }
         }
         RT_TRACE_STEP(32u + (uint32_t)CL_QUAD);
@@ -1122,7 +1127,7 @@ RT_UNROLL
           const DAAQuad qa = *(const DAAQuad*)(prog + i + 1 + PROG_QUAD_AA_UNITS * k);
           const uint32_t pos = (i << 6) + k + 1u;
           if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) {
-            tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
+            tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; best_pos = pos; best_quad = true;
           }
         }
         RT_TRACE_STEP(32u + (uint32_t)CL_QUAD_AA);

@@ -1175,7 +1175,7 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
   P.dev = sc->dev;
   if (P.head_top_bytes == 0) P.dev.head_top_nodes = 0;
   // testing knob: a wide margin sends many rays through the redo path (results must not change)
-  if (const char* e = getenv("RTX_WF_NEAR_MARGIN")) { const double v = atof(e); if (v >= 0.0 && v <= 1.0) P.dev.near_margin = v; }
+  if (const char* e = getenv("RTX_WF_NEAR_MARGIN")) { const double v = atof(e); if (v >= 1e-15 && v <= 1.0) P.dev.near_margin = v; }
   P.dev.head_end = head_end;
   // New camera paths are coherent (a wave holds one stratified sample of an 8 x 8 pixel tile): the per-ray walk with its
   // votes serves them better than the stream (final scene, camera rays only: 54.9 ms per 448 M rays through head and
