@@ -45,15 +45,16 @@ HBM_PEAK_GBS = 8000.0
 SURVEY_TRAVERSE_BYTES, SURVEY_BOUNCE_BYTES = 80, 328
 OWN_TRAVERSE_BYTES, OWN_NEW_PATH_BYTES, OWN_BOUNCE_BYTES = 100, 108, 390
 # Counter-derived constants of the profiled build (rocprofv3 --pmc passes over `RTX_WF_LANES=1 python bench.py --rows 10
-# --steps 1 --warmup 0 --no-cpu-baseline`; profiles/README.md names the commit).  Per ray segment of the whole
+# --steps 1 --warmup 0 --roofline-rows 0 --no-cpu-baseline`, tools/prof_gpu.sh; profiles/README.md names the commit).  Per ray segment of the whole
 # pipeline: VALU wave instructions, and per kernel the HBM-side bytes (FETCH_SIZE doubled as the gfx950 correction for
 # wide loads prescribes - an upper bound here, the loads are 4 and 8 bytes per lane - plus WRITE_SIZE) and the lanes
 # active per VALU instruction.
 PMC = {
-    "profile": "profiles/r1_pmc_summary.txt",
-    "valu_wave_instructions_per_segment": 73.0,
-    "traffic_bytes_per_segment": {"k_wf_traverse": (2 * 42.95e9 + 59.07e9) / 1.0699e9, "k_wf_shade": (2 * 135.8e9 + 68.89e9) / 1.0699e9},
-    "lanes_active": {"k_wf_traverse": 58, "k_wf_stream_head": 42, "k_wf_stream_deferred": 36, "k_wf_shade": 42},
+    "profile": "profiles/r2_pmc_summary.txt (one step of 10 rows, 1.06996e9 segments, one pipeline)",
+    "valu_wave_instructions_per_segment": 72.7,
+    # (2 x FETCH_SIZE + WRITE_SIZE) / segments; FETCH_SIZE as reported would give 94.3 and 191.9
+    "traffic_bytes_per_segment": {"k_wf_traverse": 134.3, "k_wf_shade": 319.3, "k_wf_stream_head": 56.6, "k_wf_stream_deferred": 15.3},
+    "lanes_active": {"k_wf_traverse": 58.2, "k_wf_stream_head": 42.7, "k_wf_stream_deferred": 34.5, "k_wf_shade": 42.6},
 }
 SIMDS, CLOCK_GHZ, F64_CYCLES_PER_WAVE_INSTRUCTION = 256 * 4, 2.4, 4   # vector f64: 16 lanes per clock per SIMD
 
