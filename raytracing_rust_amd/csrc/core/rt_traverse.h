@@ -818,32 +818,10 @@ RT_HD bool slab_hit_entry(const double* b, const LRay& r, double tmin, double tm
   entry = tmin;
   return !(tmax <= tmin);
 }
-// The same test for the nearer-child-first walk: also tells whether a box that FAILS fails only just - it would pass
-// with an upper bound larger by the relative margin RT_NEAR_MARGIN.  The decision itself is slab_hit's, bit for bit.
+// Relative margin of the nearer-child-first walk's order-dependence watch (Scene::near_margin).
 #ifndef RT_NEAR_MARGIN
 #define RT_NEAR_MARGIN 1e-9
 #endif
-RT_HD bool slab_hit_entry_margin(const double* b, const LRay& r, double tmin, double tmax, double tmax_hi, double& entry, bool& close_call) {
-  // tmax_hi = tmax plus the margin, kept by the caller.  The far planes are folded into the LARGER bound first; the
-  // decision for tmax itself then takes one more min (min is exact, so this is slab_hit's value: tmax <= tmax_hi).
-  const uint32_t nx = r.inv.x >= 0.0 ? 0u : 3u, ny = r.inv.y >= 0.0 ? 0u : 3u, nz = r.inv.z >= 0.0 ? 0u : 3u;
-  const double bnx = b[nx], bfx = b[3u - nx], bny = b[1u + ny], bfy = b[4u - ny], bnz = b[2u + nz], bfz = b[5u - nz];
-  double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
-  double nry = (bny - r.o.y) * r.inv.y, fry = (bfy - r.o.y) * r.inv.y;
-  double nrz = (bnz - r.o.z) * r.inv.z, frz = (bfz - r.o.z) * r.inv.z;
-  if (r.skip & 7u) {
-    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
-    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
-    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
-  }
-  tmin = rt_max(tmin, nrx); tmax_hi = rt_min(tmax_hi, frx);
-  tmin = rt_max(tmin, nry); tmax_hi = rt_min(tmax_hi, fry);
-  tmin = rt_max(tmin, nrz); tmax_hi = rt_min(tmax_hi, frz);
-  entry = tmin;
-  const bool pass = !(rt_min(tmax_hi, tmax) <= tmin);
-  close_call = !pass && !(tmax_hi <= tmin);   // fails with tmax, would pass with the margin added
-  return pass;
-}
 // Sphere::hit for a static sphere with an inclusive upper bound: a root equal to tmax is reported, so that the caller
 // can resolve the tie by program order (sphere_s_hit_t is this with the tie always lost, sphere.rs:99-101).
 RT_HD bool sphere_s_hit_t_incl(const DSphere& s, const V3& o, const V3& d, double tmin, double tmax, double& t) {
@@ -908,14 +886,19 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   const int bias = AHEAD ? RT_NEAR_LEAF_BIAS : RT_NEAR_LEAF_BIAS_FAR, bias_den = AHEAD ? 1 : RT_NEAR_LEAF_BIAS_FAR_DEN;
   const double tmin = 0.001;
   bool have = false, single = false, best_quad = false;
-  // Order-dependence watch.  The closest hit is the same in every visiting order as long as (a) every candidate hit
-  // lies behind the entry of the innermost box around its primitive, t > entry (then a box is only ever culled together
-  // with hits that lie behind the upper bound that culled it), and (b) no box is culled by a hair.  Rounding can break
-  // (a) where a surface touches its own box (the six axis extremes of a sphere): the box test then depends on the bound
-  // the order has reached.  A ray that meets either case within the margin is not committed: its lane walks it once
-  // more from the start in the REFERENCE's order (fixed_mode: the left child first whenever it passes; the right one,
-  // tested together with it, waits on the stack and is tested again with the bound the left subtree leaves behind,
-  // which is when and how bvh.rs:94-102 tests it).
+  // Order-dependence watch.  The closest hit is the same in every visiting order as long as every candidate hit lies
+  // behind the entry of the innermost box around its primitive, t > entry: then a box is only ever culled together
+  // with hits that lie behind the upper bound that culled it, whatever that bound was when the order got there.
+  // Rounding can break this where a surface touches its own box (the six axis extremes of a sphere): the reference's
+  // box test then depends on the bound its left-to-right order has reached.  So this walk (1) culls a box only when
+  // its entry lies beyond tmax by more than the relative margin (tmax_hi; a box within the margin is simply visited:
+  // visiting more boxes never changes a closest hit, the tie rules go by program position), and (2) marks a ray when a
+  // candidate hit does not lie behind its box's entry by more than the margin (boxes of a BVH nest exactly and rounding
+  // is monotone, so the innermost box speaks for its ancestors).  A marked ray is not committed: its lane walks it once
+  // more from the start in the REFERENCE's order (fixed_mode: exact bound; the left child first whenever it passes; the
+  // right one, tested together with it, waits on the stack and is tested again with the bound the left subtree leaves
+  // behind, which is when and how bvh.rs:94-102 tests it).  With rounding errors far below the margin, an unmarked
+  // ray's hit is the reference's: no box either order culls holds a hit that could win or tie.
   bool suspect = false, fixed_mode = false;
   double leaf_entry = -RT_INF;      // entry of the last box this lane went through
   double tmax_hi = RT_INF;          // tmax plus the margin
@@ -927,9 +910,7 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
   // a hit at t from the primitive at program position pos: does it replace the best one so far?
   auto wins = [&](double t, uint32_t pos, bool quad) {
-#if !defined(RT_WATCH_NO_LEAF)
     if (!fixed_mode && t <= leaf_entry + fabs(leaf_entry) * S.near_margin) suspect = true;
-#endif
     if (t < tmax) return true;
     if (!(t == tmax)) return false;
     if (!QUADS) return !best_quad && pos < best_pos;
@@ -1028,12 +1009,9 @@ RT_HD void walk_stream_near(const Scene& S, const uint64_t* prog, uint32_t begin
             // where the unit behind the box that is not taken is one more cache line to fetch (stress scene 79.3 -> 72.7).
             const uint64_t n0 = AHEAD ? prog[c0 + PROG_BOX_UNITS] : 0ull, n1 = (AHEAD && !single) ? prog[c1 + PROG_BOX_UNITS] : n0;
             double e0 = 0.0, e1 = 0.0;
-            bool m0 = false, m1 = false;
-            const bool p0 = slab_hit_entry_margin((const double*)(r0 + 1), lr, tmin, tmax, tmax_hi, e0, m0);
-            const bool p1 = !single && slab_hit_entry_margin((const double*)(r1 + 1), lr, tmin, tmax, tmax_hi, e1, m1);
-#if !defined(RT_WATCH_NO_CLOSE)
-            if (!fixed_mode && (m0 || (!single && m1))) suspect = true;   // a box culled by a hair
-#endif
+            const double bound = fixed_mode ? tmax : tmax_hi;          // the watch's margin, or the reference's exact bound
+            const bool p0 = slab_hit_entry((const double*)(r0 + 1), lr, tmin, bound, e0);
+            const bool p1 = !single && slab_hit_entry((const double*)(r1 + 1), lr, tmin, bound, e1);
             if (p0 || p1) {
               const bool first0 = p0 && (!p1 || fixed_mode || e0 <= e1);   // equal entries: the reference's order
               if (p0 && p1) {   // the far child waits on the stack: by heap index while it is in the table, else by position

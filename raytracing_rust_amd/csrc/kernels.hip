@@ -1127,7 +1127,7 @@ struct WfPlan {
   unsigned trav_blocks = 0, gen_blocks = 0, shade_blocks = 0;
 };
 
-static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
+static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long share) {   // share: camera paths per pipeline of the call
   const rtx_context* ctx = sc->ctx;
   WfPlan P;
   P.cap = cap;
@@ -1146,8 +1146,15 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap) {
   P.head_lds = P.head_bytes <= kLdsBudget;
   P.tail_bytes = tail_begin ? (size_t)(n_units - tail_begin) * 8 : 0;
   P.tail_lds = P.tail_bytes <= kLdsBudget;
-  const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 2);
-  P.stream_tail = tail_begin != 0 && (stream_mode < 0 || stream_mode == 1 || stream_mode == 3);
+  // ... by size: a stream is one more launch per iteration, and a call whose queues are short is all launch latency
+  // (final scene, Msamples/s streamed / not streamed: 16 M paths per call 807 / 896, 64 M 1400 / 1374, 256 M 1905 / 1698,
+  // 1 G 2167 / 1818; `quick`: 924 / 1029).  Sections that are in LDS anyway are therefore streamed only when a pipeline's
+  // share of the call is at least RTX_WF_STREAM_MIN camera paths (16 M); a section in global memory always is.
+  unsigned long long stream_min = 16ull << 20;
+  if (const char* e = getenv("RTX_WF_STREAM_MIN")) { const long long v = atoll(e); if (v >= 0) stream_min = (unsigned long long)v; }
+  const bool big = share >= stream_min;
+  const bool stream_head = sc->dev.head_end != 0 && (stream_mode < 0 ? (big || !P.head_lds) : (stream_mode == 1 || stream_mode == 2));
+  P.stream_tail = tail_begin != 0 && (stream_mode < 0 ? (big || !P.tail_lds) : (stream_mode == 1 || stream_mode == 3));
   // Sections that are binary trees of boxes over leaf records can be walked nearer child first (walk_stream_near);
   // each lane's stack (one unit position per tree level) lives in LDS.  By default (RTX_WF_NEAR=1) the deferred
   // section is, and the head section when it is too large for LDS: the stress scene's BVH of 1 M spheres and quads
@@ -1300,7 +1307,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
     l = 0;
   }
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;
-  const WfPlan P = wf_make_plan(sc, cap);
+  const WfPlan P = wf_make_plan(sc, cap, per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes));
   const unsigned long long seed = (unsigned long long)o->seed;
 
   struct Run { rtx_context::WfLane* L; hipStream_t s; WfFrame fr; int cur, k; bool done; };
@@ -1588,7 +1595,7 @@ rtx_status rtx_render_device_noalloc(rtx_scene* sc, const rtx_camera_desc* cam, 
   HIP_TRY(ctx, call_begin(ctx, stream));
   const uint32_t cap = RTX_NOALLOC_MAX_PATHS;
   const WfBuffers B = noalloc_buffers(base);
-  const WfPlan P = wf_make_plan(sc, cap);
+  const WfPlan P = wf_make_plan(sc, cap, total);
   WfFrame fr;
   fr.x0 = o->x0; fr.y0 = o->y0; fr.w = o->x1 - o->x0; fr.h = o->y1 - o->y0; fr.sample_begin = o->sample_begin; fr.per_sample = (uint32_t)per_sample;
   const int use_lights = (o->use_lights && sc->dev.has_lights) ? 1 : 0;

@@ -256,6 +256,28 @@ def test_streamed_sections_trace_the_same_paths(gpu_ctx, monkeypatch, mode):
     scene.close()
 
 
+def test_sections_are_streamed_by_call_size(gpu_ctx, monkeypatch):
+    """By default a section that lives in LDS is walked as a stream only when a pipeline's share of the call is large
+    (RTX_WF_STREAM_MIN camera paths, 16 M): a short call is launch latency, and a stream is one more launch per
+    iteration.  Either way the paths are the same."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("final", gp, width=160, spp=16, depth=40)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    out = []
+    for stream_min in ("100000", None):
+        if stream_min is None:
+            monkeypatch.delenv("RTX_WF_STREAM_MIN")
+        else:
+            monkeypatch.setenv("RTX_WF_STREAM_MIN", stream_min)
+        gpu_ctx.reset_stats()
+        out.append((scene.render(cam, rt.render_opts(cam, seed=79, pipeline=_capi.PIPELINE_WAVEFRONT)), gpu_ctx.stats()))
+    (a, sa), (b, sb) = out
+    assert sa["head_launches"] > 0 and sb["head_launches"] == 0      # 410 k paths: streamed only with the threshold lowered
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"]
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    scene.close()
+
+
 @pytest.mark.parametrize("near", ["0", "1", "2"])
 def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, near):
     """The ground of the final scene (head section) and its sphere cluster (deferred section) are binary trees of boxes
@@ -271,6 +293,7 @@ def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, 
     a = scene.render(cam, rt.render_opts(cam, seed=90, pipeline=_capi.PIPELINE_FUSED))
     sa = gpu_ctx.stats()
     monkeypatch.setenv("RTX_WF_NEAR", near)
+    monkeypatch.setenv("RTX_WF_STREAM", "1")   # a call this small would not stream its sections by itself
     gpu_ctx.reset_stats()
     b = scene.render(cam, rt.render_opts(cam, seed=90, pipeline=_capi.PIPELINE_WAVEFRONT))
     sb = gpu_ctx.stats()
@@ -291,6 +314,7 @@ def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
     both edges."""
     if near is not None:
         monkeypatch.setenv("RTX_WF_NEAR", near)
+    monkeypatch.setenv("RTX_WF_STREAM", "1")   # sections as streams (a call this small would walk them per ray by itself)
     gp = rt.Graph()
     wp, _, _ = recipe(gp)
     cam = rt.initialize_camera(rt.camera_desc(aspect_ratio=97.0 / 61.0, image_width=97, samples_per_pixel=9, max_depth=12,
@@ -325,6 +349,7 @@ def test_rays_handed_back_by_the_nearer_child_first_walk_change_nothing(gpu_ctx,
     a = scene.render(cam, rt.render_opts(cam, seed=91, pipeline=_capi.PIPELINE_FUSED))
     sa = gpu_ctx.stats()
     monkeypatch.setenv("RTX_WF_NEAR", near)
+    monkeypatch.setenv("RTX_WF_STREAM", "1")
     for margin, lo, hi in (("0.05", 1000, None), (None, 0, 20)):
         if margin is not None:
             monkeypatch.setenv("RTX_WF_NEAR_MARGIN", margin)

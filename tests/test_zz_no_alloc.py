@@ -26,8 +26,10 @@ def _both(scene, ctx, cam, opts):
     return a.numpy(), sa, b.numpy(), sb
 
 
-@pytest.mark.parametrize("name", ["final", "smoke", "cornell"])
-def test_noalloc_matches_render_device_twice_in_a_row(gpu_ctx, name):
+@pytest.mark.parametrize("name,stream", [("final", None), ("final", "1"), ("smoke", None), ("cornell", None)])
+def test_noalloc_matches_render_device_twice_in_a_row(gpu_ctx, monkeypatch, name, stream):
+    if stream is not None:
+        monkeypatch.setenv("RTX_WF_STREAM", stream)   # the sections of the final scene as streams too (calls this small walk them per ray)
     g = rt.Graph()
     w, l, cam = scenes.build(name, g, width=96, spp=16, depth=30)
     scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
