@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #include "rt_traverse.h"
@@ -47,8 +48,11 @@ struct CompiledProgram {
   uint32_t head_near_depth = 0;    // > 0: so is the head section under its root box
   uint32_t tail_near_quads = 0;    // the deferred section's leaves hold quads (it needs the walk's quad classes)
   uint32_t defer_pos = 0;          // unit index of the DEFER unit
-  uint32_t head_top_begin = 0, head_top_nodes = 0;   // Scene::head_top_*: the first levels of the head section's box tree
+  uint32_t prog_units = 0;         // units of the program itself; tables for particular walks follow in `units`
+  uint32_t head_top_begin = 0, head_top_nodes = 0, head_top_units = 0;   // Scene::head_top_*: the first levels of the head section's box tree
   uint32_t head_top_max_levels = 10;                 // 1023 records = 57 KB of LDS next to the walk's stacks
+  uint32_t head_wide_begin = 0, head_wide_nodes = 0, head_wide_depth = 0; // Scene::head_wide_*: the head section's box tree, two levels per record
+  bool head_wide = true;                             // build that table (tests switch it off to compare)
 
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
   // a medium boundary).
@@ -100,7 +104,9 @@ struct CompiledProgram {
     }
     if (units.size() & 1u) units.push_back(nop());  // even unit count: the image is copied in 16-byte pieces
     units.insert(units.end(), 8, nop());            // tail pad: the successor prefetch of a box may read past END
+    prog_units = (uint32_t)units.size();
     build_head_top();
+    build_head_wide();
   }
 
   // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
@@ -110,9 +116,10 @@ struct CompiledProgram {
     S.nodes = nullptr; S.n_nodes = 0;
     S.world_begin = world_begin; S.world_end = 0;
     S.media = media.data();
-    S.prog = units.data(); S.n_units = (uint32_t)units.size(); S.tail_begin = tail_begin;
+    S.prog = units.data(); S.n_units = prog_units; S.tail_begin = tail_begin;
     S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr; S.near_margin = RT_NEAR_MARGIN;
-    S.head_top_begin = head_top_begin; S.head_top_nodes = head_top_nodes;
+    S.head_top_begin = head_top_begin; S.head_top_nodes = head_top_nodes; S.head_top_units = head_top_units;
+    S.head_wide_begin = head_wide_begin; S.head_wide_nodes = head_wide_nodes; S.head_wide_depth = head_wide_depth;
     return S;
   }
 
@@ -158,7 +165,7 @@ struct CompiledProgram {
   // head_top_max_levels) as consist of boxes with two box children each.  Only for a head section that has the
   // nearer-child-first shape and is too large to be staged whole (a section that fits LDS is read from there anyway).
   void build_head_top() {
-    head_top_begin = 0; head_top_nodes = 0;
+    head_top_begin = 0; head_top_nodes = 0; head_top_units = 0;
     if (!head_end || head_near_depth == 0 || (size_t)head_end * 8 <= 160u * 1024u) return;
     auto is_box = [&](uint32_t p) { return p < head_end && RTX_NODE_KIND((uint32_t)units[p]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)units[p]) != PROG_GUARD_IDX; };
     std::vector<uint32_t> pos{world_begin};
@@ -190,6 +197,56 @@ struct CompiledProgram {
     if (units.size() & 1u) units.push_back(nop());
     for (uint32_t h = 0; h < head_top_nodes; h += 2) units.push_back((uint64_t)pos[h] | ((uint64_t)(h + 1 < head_top_nodes ? pos[h + 1] : 0u) << 32));
     if (units.size() & 1u) units.push_back(nop());
+    head_top_units = (uint32_t)units.size() - head_top_begin;
+  }
+  // The box tree of such a head section with two levels folded into one, appended to the image for the walk from
+  // global memory (walk_stream_wide): a record of PROG_WIDE_UNITS units (256 bytes, 256-byte aligned) per box that has
+  // two box children, holding the boxes of its (up to four) grandchildren, or of a child itself where that child is a
+  // leaf, in the program's order, each with a descriptor: the record of the slot's own box when that has box children
+  // (low word, high word 0), or where its leaf units begin and end in the program (low and high word; the end is
+  // never 0), or PROG_WIDE_EMPTY.  Records lie in depth-first order like the program (a subtree is one stretch of
+  // memory); record 0 belongs to the section's root box.  A box test that is skipped this way (a child with box
+  // children) cannot change what the walk finds: a box contains its children's boxes exactly (aabb.rs:38-45 takes
+  // minima and maxima) and every operation of Aabb::hit is monotone in the bounds, so a ray that passes a box passes
+  // every box around it for the same interval.
+  void build_head_wide() {
+    head_wide_begin = 0; head_wide_nodes = 0; head_wide_depth = 0;
+    uint32_t depth = 0;
+    if (!head_wide || !head_end || head_near_depth == 0 || (size_t)head_end * 8 <= 160u * 1024u) return;
+    auto is_box = [&](uint32_t p) { return p < head_end && RTX_NODE_KIND((uint32_t)units[p]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)units[p]) != PROG_GUARD_IDX; };
+    auto inner = [&](uint32_t p) { return is_box(p) && is_box(p + PROG_BOX_UNITS) && is_box((uint32_t)(units[p + PROG_BOX_UNITS] >> 32)); };
+    if (!inner(world_begin)) return;
+    std::vector<uint64_t> table;
+    bool ok = true;
+    // emits the record of inner box p (and, behind it, the records of its inner slots); returns its index
+    std::function<uint32_t(uint32_t, int)> emit = [&](uint32_t p, int level) -> uint32_t {
+      const uint32_t me = (uint32_t)(table.size() / PROG_WIDE_UNITS);
+      if (level > 40 || me >= (1u << 27)) { ok = false; return 0u; }
+      depth = std::max(depth, (uint32_t)level + 1u);
+      table.insert(table.end(), PROG_WIDE_UNITS, 0ull);
+      uint32_t slots[4], n = 0;
+      const uint32_t c0 = p + PROG_BOX_UNITS, c1 = (uint32_t)(units[c0] >> 32);
+      for (uint32_t c : {c0, c1}) {
+        if (inner(c)) { slots[n++] = c + PROG_BOX_UNITS; slots[n++] = (uint32_t)(units[c + PROG_BOX_UNITS] >> 32); }
+        else slots[n++] = c;
+      }
+      for (uint32_t k = 0; k < 4; ++k) {
+        uint64_t desc = PROG_WIDE_EMPTY;
+        if (k < n) {
+          const uint32_t q = slots[k];
+          for (uint32_t j = 0; j < 6; ++j) table[(size_t)me * PROG_WIDE_UNITS + 6 * k + j] = units[q + 1 + j];
+          if (inner(q)) desc = (uint64_t)emit(q, level + 1);
+          else desc = (uint64_t)(q + PROG_BOX_UNITS) | ((units[q] >> 32) << 32);
+        }
+        table[(size_t)me * PROG_WIDE_UNITS + 24 + k] = desc;
+      }
+      return me;
+    };
+    emit(world_begin, 0);
+    while (units.size() & 31u) units.push_back(nop());
+    if (!ok || units.size() + table.size() + 64u >= (1ull << 32)) return;
+    head_wide_begin = (uint32_t)units.size(); head_wide_nodes = (uint32_t)(table.size() / PROG_WIDE_UNITS); head_wide_depth = depth;
+    units.insert(units.end(), table.begin(), table.end());
   }
   static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }
   static uint64_t bits(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }

@@ -72,9 +72,16 @@ struct Scene : rtx_scene_desc {
   double near_margin;   // relative margin of the nearer-child-first walk's order-dependence watch (RT_NEAR_MARGIN by default)
   // Top of the head section's box tree, for a walk of a program that stays in global memory: copies of the box records
   // of its first levels in heap order (root 0, children of h at 2h+1 and 2h+2), 7 units each, at unit head_top_begin of
-  // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none.
-  uint32_t head_top_begin, head_top_nodes;
+  // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none;
+  // head_top_units = units of the whole table.  (n_units counts the program only: the tables lie behind it.)
+  uint32_t head_top_begin, head_top_nodes, head_top_units;
+  // The head section's box tree with two levels folded into one (CompiledProgram::build_head_wide), for the walk of a
+  // section that stays in global memory: head_wide_nodes records of PROG_WIDE_UNITS units from unit head_wide_begin
+  // (a multiple of 32: records are 256-byte aligned), the root's children first.  0 nodes = none.
+  uint32_t head_wide_begin, head_wide_nodes, head_wide_depth;   // depth: records on the longest way down
 };
+#define PROG_WIDE_UNITS 32u                // four boxes (6 units each), four slot descriptors, four spare units
+#define PROG_WIDE_EMPTY 0xFFFFFFFFFFFFFFFFull   // slot descriptor: no box in this slot
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
 #define PROG_SPHERE_S_UNITS 4u   // per sphere of a run (DSphere)
@@ -1113,6 +1120,220 @@ RT_UNROLL
       }
     }
     if (next != i) { i = next; unit = prog[i < end ? i : begin]; }
+  }
+}
+
+// walk_stream_near for a head section that stays in global memory, over the table that folds two levels of its box
+// tree into one record (Scene::head_wide_*, CompiledProgram::build_head_wide): a lane reads the (up to) four boxes of
+// a record at once, 256 bytes at one address, tests them all, goes on with the nearest one that passes and leaves the
+// others on its stack, farthest first.  The tree is walked in half as many dependent memory round trips as box by box,
+// which is what bounds a walk whose every level is a cache miss.  Leaves are the program's: a leaf slot says where its
+// units lie, they are tested as in walk_stream_near (same classes, same tie rules by program position, same watch:
+// a candidate hit that does not lie behind the entry of its leaf's box by more than the margin marks the ray).
+// A marked ray, and any ray that is not finite, is walked again by its lane alone over the PROGRAM in the reference's
+// order (bvh.rs:94-102) with the exact bound, which is what is committed for it.
+//   stk: per-lane stack (lane-private, stk[level * stk_stride]), 3 entries per level of the table
+//        (Scene::head_wide_depth); an entry is the record of a slot with box children, or 0x80000000 | record << 2 |
+//        slot for a leaf slot, whose box is tested again (with the bound of that moment) when the entry is taken.
+//   begin: the section's root box in the program (tested first, alone); wide: the table.
+#ifndef RT_WIDE_REFILL
+#define RT_WIDE_REFILL RT_NEAR_REFILL
+#endif
+#ifndef RT_WIDE_LEAF_BIAS
+#define RT_WIDE_LEAF_BIAS RT_NEAR_LEAF_BIAS_FAR
+#endif
+#ifndef RT_WIDE_LEAF_BIAS_DEN
+#define RT_WIDE_LEAF_BIAS_DEN RT_NEAR_LEAF_BIAS_FAR_DEN
+#endif
+template <bool QUADS, class Feed>
+RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, const uint64_t* wide) {
+  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_QUAD = 4, CL_BOX6 = 7, CL_NODE = 8, CL_DONE = 10 };
+  enum { ST_NODE = 0, ST_SLOT = 1, ST_LEAF = 2, ST_POP = 3 };
+  const int bias = RT_WIDE_LEAF_BIAS, bias_den = RT_WIDE_LEAF_BIAS_DEN;
+  const double tmin = 0.001;
+  bool have = false, best_quad = false, suspect = false, fixed_mode = false;
+  double leaf_entry = -RT_INF, tmax_hi = RT_INF, tmax = RT_INF;
+  uint32_t id = 0, st = ST_POP, node = 0, slot = 0, i = begin, end = 0, sp = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
+  uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  auto rs = feed.ray(0);
+  LRay lr;
+  lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  auto wins = [&](double t, uint32_t pos, bool quad) {   // as in walk_stream_near
+    if (!fixed_mode && t <= leaf_entry + fabs(leaf_entry) * S.near_margin) suspect = true;
+    if (t < tmax) return true;
+    if (!(t == tmax)) return false;
+    if (!QUADS) return !best_quad && pos < best_pos;
+    if (quad != best_quad) return quad;
+    return quad ? pos > best_pos : pos < best_pos;
+  };
+  auto take_hit = [&](double t, uint32_t kind_idx, uint32_t pos, bool quad) {
+    tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = kind_idx; hit_ctx = 0; best_pos = pos; best_quad = quad;
+  };
+  // one leaf record at unit p, every primitive of it (any class); returns the record's size in units
+  auto leaf_record = [&](uint32_t p, uint64_t u) -> uint32_t {
+    const uint32_t kind = RTX_NODE_KIND((uint32_t)u), idx = RTX_NODE_IDX((uint32_t)u), count = (uint32_t)(u >> 32);
+    double t;
+    if (kind == PROG_NODE_SPHERE_S) {
+      for (uint32_t k = 0; k < count; ++k) {
+        const DSphere sph = *(const DSphere*)(prog + p + 1 + PROG_SPHERE_S_UNITS * k);
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, false)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k), pos, false);
+      }
+      return 1u + PROG_SPHERE_S_UNITS * count;
+    }
+    if (QUADS && (kind == RTX_NODE_QUAD || ((lr.skip & 8u) && (kind == PROG_NODE_QUAD_AA || kind == PROG_NODE_BOX6)))) {
+      uint32_t cnt = 1u, size = 1u;
+      if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
+      else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
+      }
+      return size;
+    }
+    if (QUADS && kind == PROG_NODE_BOX6) {
+      const DBox6 bx = *(const DBox6*)(prog + p + 1);
+      for (int f = 0; f < 6; ++f) {
+        const uint32_t pos = (p << 6) + (uint32_t)f + 1u;
+        if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f), pos, true);
+      }
+      return PROG_BOX6_UNITS;
+    }
+    if (QUADS && kind == PROG_NODE_QUAD_AA) {
+      for (uint32_t k = 0; k < count; ++k) {
+        const DAAQuad qa = *(const DAAQuad*)(prog + p + 1 + PROG_QUAD_AA_UNITS * k);
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
+      }
+      return 1u + PROG_QUAD_AA_UNITS * count;
+    }
+    return prog_record_units(u);
+  };
+  for (;;) {
+    if (have && (st == ST_POP || (st == ST_LEAF && i >= end))) {   // out of units: the nearest box left behind, or hand in
+      if (sp == 0) {
+        if (suspect) {   // once more over the program, this lane alone, in the reference's order
+          feed.note_redo();
+          feed.start(id, tmax, hit_kind, hit_ctx);
+          fixed_mode = true; suspect = false; best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
+          for (uint32_t p = begin;;) {
+            const uint64_t u = prog[p];
+            const uint32_t k = RTX_NODE_KIND((uint32_t)u);
+            if (k == PROG_NODE_END || k == PROG_NODE_SYNC) break;
+            if (k == RTX_NODE_BOX) p = slab_hit((const double*)(prog + p + 1), lr, tmin, tmax) ? p + PROG_BOX_UNITS : (uint32_t)(u >> 32);
+            else p += leaf_record(p, u);
+          }
+          fixed_mode = false;
+        }
+        feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
+      } else {
+        sp -= 1;
+        const uint32_t e = stk[sp * stk_stride];
+        if (e & 0x80000000u) { node = (e & 0x7FFFFFFFu) >> 2; slot = e & 3u; st = ST_SLOT; }
+        else { node = e; st = ST_NODE; }
+      }
+    }
+    if (feed.more() && RT_WAVE_COUNT(!have) >= RT_WIDE_REFILL) {
+      uint32_t nid = 0;
+      if (feed.take(!have, nid)) {
+        id = nid; rs = feed.ray(id);
+        feed.start(id, tmax, hit_kind, hit_ctx); tmax_hi = tmax + tmax * S.near_margin;
+        lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
+        have = true; sp = 0; suspect = (lr.skip & 8u) != 0u; fixed_mode = false; leaf_entry = -RT_INF;
+        best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
+        // the root box, alone; its children are the table's first record
+        node = 0; st = (!suspect && slab_hit((const double*)(prog + begin + 1), lr, tmin, tmax_hi)) ? ST_NODE : ST_POP;
+      }
+    }
+    if (!RT_WAVE_ANY(have)) {
+      if (feed.more()) continue;
+      break;
+    }
+    const uint32_t kind = RTX_NODE_KIND((uint32_t)unit);
+    int cls = CL_CHEAP;
+    if (!have || st == ST_POP || (st == ST_LEAF && i >= end)) cls = CL_DONE;
+    else if (st != ST_LEAF) cls = CL_NODE;
+    else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
+    else if (QUADS && kind == PROG_NODE_BOX6) cls = (lr.skip & 8u) ? CL_QUAD : CL_BOX6;
+    else if (QUADS && kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
+    else if (QUADS && kind == RTX_NODE_QUAD) cls = CL_QUAD;
+    if (RT_WAVE_ANY(cls == CL_CHEAP)) {
+      if (cls == CL_CHEAP) {   // fillers, and the guard box in front of a BOX6 record: on to the record, or past it
+        if (kind == RTX_NODE_BOX) i = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax) ? i + PROG_BOX_UNITS : (uint32_t)(unit >> 32);
+        else i += prog_record_units(unit);
+        unit = prog[i < end ? i : begin];
+      }
+      continue;
+    }
+    const int n_x = RT_WAVE_COUNT(cls == CL_NODE), n_ss = RT_WAVE_COUNT(cls == CL_SPHERE_S);
+    const int n_b = QUADS ? RT_WAVE_COUNT(cls == CL_BOX6) : 0, n_a = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD_AA) : 0, n_q = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD) : 0;
+    const int n_leaf = n_ss + n_b + n_a + n_q;
+    if (n_leaf == 0 && n_x == 0) continue;   // only lanes that hand in or take from their stacks
+    if (n_x > 0 && (n_leaf == 0 || n_x * bias >= n_leaf * bias_den)) {
+      bool on_node = cls == CL_NODE;
+      int nb, ns, nd;
+      do {
+        if (on_node) {
+          const uint64_t* nd_ = wide + (size_t)node * PROG_WIDE_UNITS;
+          if (st == ST_SLOT) {   // a leaf slot taken from the stack: its box once more, with the bound of now
+            double e;
+            const uint64_t dsc = nd_[24u + slot];
+            if (slab_hit_entry((const double*)(nd_ + 6u * slot), lr, tmin, tmax_hi, e)) {
+              leaf_entry = e; i = (uint32_t)dsc; end = (uint32_t)(dsc >> 32); unit = prog[i]; st = ST_LEAF;
+            } else st = ST_POP;
+          } else {
+            double e0 = RT_INF, e1 = RT_INF, e2 = RT_INF, e3 = RT_INF;
+            const uint64_t d0 = nd_[24], d1 = nd_[25], d2 = nd_[26], d3 = nd_[27];
+            if (!(d0 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_), lr, tmin, tmax_hi, e0))) e0 = RT_INF;
+            if (!(d1 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 6), lr, tmin, tmax_hi, e1))) e1 = RT_INF;
+            if (!(d2 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 12), lr, tmin, tmax_hi, e2))) e2 = RT_INF;
+            if (!(d3 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 18), lr, tmin, tmax_hi, e3))) e3 = RT_INF;
+            // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
+            // (an entry is finite: the bound it was tested against is)
+            uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
+#define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const double te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
+            RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)
+#undef RT_WIDE_CE
+            auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
+            auto push = [&](uint32_t k) {
+              const uint64_t dsc = desc_of(k);
+              stk[sp * stk_stride] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (node << 2) | k);
+              sp += 1;
+            };
+            if (e3 < RT_INF) push(k3);
+            if (e2 < RT_INF) push(k2);
+            if (e1 < RT_INF) push(k1);
+            if (e0 < RT_INF) {
+              const uint64_t dsc = desc_of(k0);
+              if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
+              else { leaf_entry = e0; i = (uint32_t)dsc; end = (uint32_t)(dsc >> 32); unit = prog[i]; st = ST_LEAF; }
+            } else st = ST_POP;
+          }
+          if (st == ST_POP && sp > 0) {   // nothing here: on to the nearest box left behind
+            sp -= 1;
+            const uint32_t e = stk[sp * stk_stride];
+            if (e & 0x80000000u) { node = (e & 0x7FFFFFFFu) >> 2; slot = e & 3u; st = ST_SLOT; }
+            else { node = e; st = ST_NODE; }
+          }
+          RT_TRACE_STEP(RTX_NODE_BOX);
+        }
+        const bool fin = !have || st == ST_POP || (st == ST_LEAF && i >= end);
+        on_node = !fin && st != ST_LEAF;
+        nb = RT_WAVE_COUNT(on_node); nd = RT_WAVE_COUNT(fin);
+        ns = RT_WAVE_LANES - nb - nd;
+      } while (nb > 0 && (ns == 0 || nb * bias >= ns * bias_den) && !(nd >= RT_WIDE_REFILL));
+      continue;
+    }
+    // leaves: the class most lanes wait for
+    int pick = CL_SPHERE_S, best_n = n_ss;
+    if (QUADS && n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
+    if (QUADS && n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
+    if (QUADS && n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
+    if (cls == pick) {
+      i += leaf_record(i, unit);
+      RT_TRACE_STEP(32u + (uint32_t)pick);
+      unit = prog[i < end ? i : begin];
+    }
   }
 }
 

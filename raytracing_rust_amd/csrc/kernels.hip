@@ -423,14 +423,17 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
   feed.wnext = 0; feed.wend = 0; feed.seen = 0; feed.more_ = true; feed.from_hits = TAIL;
   if (NEAR) {  // the section's box tree nearer child first; the lanes' stacks sit behind the staged program
     uint32_t* stk = (uint32_t*)(lds_prog + (USE_LDS ? end_unit - first_unit : 0u)) + threadIdx.x;
-    if (!USE_LDS && !TAIL && NEAR == 2 && S.head_top_nodes) {
+    if (!USE_LDS && !TAIL && NEAR == 2 && S.head_wide_nodes) {
+      // a head section walked from global memory through the table that folds two levels of its tree into one record
+      walk_stream_wide<true>(S, prog, S.world_begin, feed, stk, blockDim.x, S.prog + S.head_wide_begin);
+    } else if (!USE_LDS && !TAIL && NEAR == 2 && S.head_top_nodes) {
       // a head section walked from global memory: the first levels of its tree (heap order, with their unit positions)
       // are staged behind the stacks, so that the walk leaves LDS only below them
       uint64_t* top = lds_prog + (size_t)S.head_near_depth * (blockDim.x / 2u);
-      const uint32_t box_units = (S.head_top_nodes * PROG_BOX_UNITS + 1u) & ~1u, all_units = S.n_units - S.head_top_begin;
+      const uint32_t box_units = (S.head_top_nodes * PROG_BOX_UNITS + 1u) & ~1u, all_units = S.head_top_units;
       for (uint32_t k = threadIdx.x; k < all_units; k += blockDim.x) top[k] = S.prog[S.head_top_begin + k];
       __syncthreads();
-      walk_stream_near<true, false, true>(S, prog, S.world_begin, feed, stk, blockDim.x, true, top, (const uint32_t*)(top + box_units), S.head_top_nodes);
+      walk_stream_near<true, false, 1>(S, prog, S.world_begin, feed, stk, blockDim.x, true, top, (const uint32_t*)(top + box_units), S.head_top_nodes);
     } else {
       walk_stream_near<NEAR == 2, USE_LDS>(S, prog, TAIL ? S.tail_begin : S.world_begin, feed, stk, blockDim.x, !TAIL);
     }
@@ -1174,13 +1177,20 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
   P.near_head_stack = (size_t)sc->dev.head_near_depth * RT_TRAV_THREADS * sizeof(uint32_t);
   P.near_head_lds = near_head_ok && P.head_lds && P.head_bytes + P.near_head_stack <= kLdsBudget;
   P.near_head_global = near_head_ok && !P.head_lds && P.near_head_stack <= kLdsBudget;
-  P.head_top_bytes = (size_t)(sc->dev.head_top_nodes ? sc->dev.n_units - sc->dev.head_top_begin : 0u) * 8;
+  P.head_top_bytes = (size_t)(sc->dev.head_top_nodes ? sc->dev.head_top_units : 0u) * 8;
   const char* top_env = getenv("RTX_WF_TOP");   // 0: walk the whole head section from global memory
-  if (!P.near_head_global || P.near_head_stack + P.head_top_bytes > kLdsBudget || (top_env && atoi(top_env) == 0)) P.head_top_bytes = 0;
+  // ... or all of it through the table that folds two levels into one record (walk_stream_wide; RTX_WF_WIDE=0: not),
+  // whose stack takes three entries per record on the way down
+  const char* wide_env = getenv("RTX_WF_WIDE");
+  const size_t wide_stack = (size_t)sc->dev.head_wide_depth * 3u * RT_TRAV_THREADS * sizeof(uint32_t);
+  const bool use_wide = stream_head && sc->dev.head_wide_nodes != 0 && near_mode != 0 && !P.head_lds && wide_stack <= kLdsBudget && !(wide_env && atoi(wide_env) == 0);
+  if (use_wide) { P.near_head_global = true; P.near_head_stack = wide_stack; }
+  if (!P.near_head_global || use_wide || P.near_head_stack + P.head_top_bytes > kLdsBudget || (top_env && atoi(top_env) == 0)) P.head_top_bytes = 0;
   const uint32_t head_end = stream_head ? sc->dev.head_end : 0u;
   P.head_end = head_end;
   P.dev = sc->dev;
   if (P.head_top_bytes == 0) P.dev.head_top_nodes = 0;
+  if (!use_wide) P.dev.head_wide_nodes = 0;
   // testing knob: a wide margin sends many rays through the redo path (results must not change)
   if (const char* e = getenv("RTX_WF_NEAR_MARGIN")) { const double v = atof(e); if (v >= 1e-15 && v <= 1.0) P.dev.near_margin = v; }
   P.dev.head_end = head_end;
@@ -1498,8 +1508,9 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   static_cast<rtx_scene_desc&>(sc->dev) = *d;
   sc->dev.nodes = nullptr; sc->dev.n_nodes = 0;
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
-  sc->dev.n_units = (uint32_t)prog.units.size(); sc->dev.tail_begin = prog.tail_begin;
-  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN; sc->dev.head_top_begin = prog.head_top_begin; sc->dev.head_top_nodes = prog.head_top_nodes;
+  sc->dev.n_units = prog.prog_units; sc->dev.tail_begin = prog.tail_begin;
+  sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN; sc->dev.head_top_begin = prog.head_top_begin; sc->dev.head_top_nodes = prog.head_top_nodes; sc->dev.head_top_units = prog.head_top_units;
+  sc->dev.head_wide_begin = prog.head_wide_begin; sc->dev.head_wide_nodes = prog.head_wide_nodes; sc->dev.head_wide_depth = prog.head_wide_depth;
   sc->n_general_media = prog.n_general_media;
   sc->nothing_behind_head = false;
   if (prog.head_end && !prog.tail_begin && d->n_media == 0) {

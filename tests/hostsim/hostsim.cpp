@@ -18,7 +18,9 @@ static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 using namespace rt;
 
 static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true;  // compile options under test
-static int g_near_walks = 0, g_top_walks = 0;
+static int g_near_walks = 0, g_top_walks = 0, g_wide_walks = 0;
+static double g_near_margin = 0.0;
+static int g_head_table = 2;  // head section in global memory: 2 = the folded table when the program has one, 1 = first levels in heap order, 0 = neither
 static int g_near = 0;  // staged walk: 1 = the deferred section nearer child first, 2 = the head section too
 
 extern "C" {
@@ -80,7 +82,8 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
                          uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
   prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
-  const Scene S = prog.host_view(*desc);
+  Scene S = prog.host_view(*desc);
+  if (g_near_margin > 0.0) S.near_margin = g_near_margin;
   if (!S.head_end && !S.tail_begin) return -1;
   std::vector<Hit> hits(n);
   std::vector<uint32_t> deferred;
@@ -89,7 +92,11 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
     HostFeed feed{rays, nullptr, n, 0, hits.data(), false, &redos};
     std::vector<uint32_t> stk(S.head_near_depth + 1u);
     if (g_near == 2 && S.head_near_depth > 0) {
-      if (S.head_top_nodes) {   // as the GPU walks a head section that stays in global memory: first levels from the table
+      if (S.head_wide_nodes && g_head_table == 2) {   // as the GPU walks it by default: two levels of the tree per step
+        std::vector<uint32_t> wstk(3u * S.head_wide_depth + 1u);
+        walk_stream_wide<true>(S, S.prog, S.world_begin, feed, wstk.data(), 1u, S.prog + S.head_wide_begin);
+        g_wide_walks += 1;
+      } else if (S.head_top_nodes && g_head_table >= 1) {   // as the GPU walks a head section that stays in global memory: first levels from the table
         const uint64_t* top = S.prog + S.head_top_begin;
         const uint32_t box_units = (S.head_top_nodes * PROG_BOX_UNITS + 1u) & ~1u;
         walk_stream_near<true, false, true>(S, S.prog, S.world_begin, feed, stk.data(), 1u, true, top, (const uint32_t*)(top + box_units), S.head_top_nodes);
@@ -143,6 +150,9 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
 
 void sim_set_near(int mode) { g_near = mode; }
 int sim_near_walks(void) { return g_near_walks; }
+void sim_set_head_table(int mode) { g_head_table = mode; }
+void sim_set_near_margin(double m) { g_near_margin = m; }   // the order watch's relative margin (0 = the default)
+int sim_wide_walks(void) { return g_wide_walks; }      // head sections walked through the folded table, so far
 int sim_top_walks(void) { return g_top_walks; }        // head sections walked with their first levels from the heap-ordered table, so far
 int sim_order_redos(void) { return g_redos; }          // rays of the last staged walk that went through the fixed order again   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }

@@ -336,12 +336,11 @@ def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
 @pytest.mark.parametrize("name,kw,near", [("final", dict(width=240, spp=16, depth=30), "2"),
                                           ("stress", dict(width=320, spp=4, depth=12, n_prims=200000), "1")])
 def test_rays_handed_back_by_the_nearer_child_first_walk_change_nothing(gpu_ctx, monkeypatch, name, kw, near):
-    """The nearer-child-first walks hand a ray back to a walk in the reference's order when its result might depend on
-    the visiting order (a hit not clearly behind its box's entry, a box culled by a hair: relative margin 1e-9).  With
-    the margin widened to 5 % (RTX_WF_NEAR_MARGIN, a testing knob) a large share of the rays takes that way, through the
-    redo list and the extra launch, in the deferred section and (final scene: RTX_WF_NEAR=2; stress scene: by default) in
-    the head section; the paths must still be the fused pipeline's.  With the default margin random camera paths
-    essentially never qualify."""
+    """The nearer-child-first walks walk a ray once more, in the reference's order, when its result might depend on
+    the visiting order (a hit not clearly behind its box's entry: relative margin 1e-9).  With the margin widened to
+    5 % (RTX_WF_NEAR_MARGIN, a testing knob) a large share of the rays takes that way, in the deferred section and
+    (final scene: RTX_WF_NEAR=2; stress scene: by default, over the folded table of its BVH) in the head section; the
+    paths must still be the fused pipeline's.  With the default margin random camera paths essentially never qualify."""
     gp = rt.Graph()
     wp, lp, cam = scenes.build(name, gp, **kw)
     scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)

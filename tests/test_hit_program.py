@@ -1,5 +1,7 @@
 """CPU tier: the flattened hit program (host layer + device core compiled for the host) against the oracle's
 recursive trait-object traversal.  Bit-exact first-hit AOVs; BVH shape; bounding boxes."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -93,13 +95,22 @@ def test_nearer_child_first_finds_the_same_hits(name):
         wp, lp, rays = recipes.ties_in_box_trees(gp)
     d = rt.flatten(gp, wp, lp)
     whole = H.hostsim_first_hit(d, rays)
-    for near, walks in ((1, 0 if name == "stress" else 1), (2, 1 if name == "stress" else 2)):
-        tops = H.hostsim_lib().sim_top_walks()
-        staged, streamed = H.hostsim_first_hit_staged(d, rays, near=near)
-        assert H.hostsim_lib().sim_near_walks() == walks
-        # the stress scene's BVH does not fit LDS: its first levels are read from the heap-ordered table (same walk)
-        assert H.hostsim_lib().sim_top_walks() - tops == (1 if name == "stress" and near == 2 else 0)
-        H.assert_aov_equal(whole, staged, f"{name} near={near}")
+    lib = H.hostsim_lib()
+    # the stress scene's BVH does not fit LDS; its boxes are then read from a table: two levels of the tree folded into
+    # one record (table 2, the default), or the first levels in heap order (1), or from the program (0).  Same hits.
+    for near, walks, table in ((1, 0 if name == "stress" else 1, 2), (2, 1 if name == "stress" else 2, 2), (2, 1 if name == "stress" else 2, 1),
+                               (2, 1 if name == "stress" else 2, 0)):
+        tops, wides = lib.sim_top_walks(), lib.sim_wide_walks()
+        lib.sim_set_head_table(table)
+        try:
+            staged, streamed = H.hostsim_first_hit_staged(d, rays, near=near)
+        finally:
+            lib.sim_set_head_table(2)
+        assert lib.sim_near_walks() == walks
+        through = name == "stress" and near == 2
+        assert lib.sim_wide_walks() - wides == (1 if through and table == 2 else 0)
+        assert lib.sim_top_walks() - tops == (1 if through and table == 1 else 0)
+        H.assert_aov_equal(whole, staged, f"{name} near={near} table={table}")
         assert streamed >= len(rays)
     hit = np.isfinite(whole["t"])
     assert hit.sum() > 1500
@@ -107,6 +118,34 @@ def test_nearer_child_first_finds_the_same_hits(name):
         ids = set(np.unique(whole["prim_id"][hit]).tolist())
         quads = [6 * 64 + 2 * k for k in range(16)]              # creation ordinals: 64 boxes of six faces, then the quad pairs
         assert sum((q in ids) + (q + 1 in ids) for q in quads) == sum((q in ids) or (q + 1 in ids) for q in quads) >= 12
+
+
+def test_folded_table_walk_hands_rays_back_to_the_program_order():
+    """The walk over the folded table (walk_stream_wide) re-walks a ray it cannot vouch for over the program itself,
+    in the reference's order.  With the watch's margin opened wide most rays whose hit lies near the entry of its
+    leaf box go that way; the hits must not change, bit for bit."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("stress", gp, width=160, n_prims=30000)
+    rng = np.random.default_rng(33)
+    sec = np.concatenate([rng.uniform(-1000.0, 1000.0, (8000, 3)), rng.normal(size=(8000, 3)), rng.uniform(0, 1, (8000, 1))], axis=1)
+    rays = np.concatenate([rt.pixel_center_rays(cam, time=0.2), sec])
+    rays[5, 3] = np.inf                                     # a ray that is not finite goes the program's way at once
+    d = rt.flatten(gp, wp, lp)
+    whole = H.hostsim_first_hit(d, rays)
+    lib = H.hostsim_lib()
+    lib.sim_set_near_margin.argtypes = [ctypes.c_double]
+    seen = []
+    for margin in (0.0, 0.05, 1.0):
+        lib.sim_set_near_margin(margin)
+        try:
+            wides = lib.sim_wide_walks()
+            staged, _ = H.hostsim_first_hit_staged(d, rays, near=2)
+        finally:
+            lib.sim_set_near_margin(0.0)
+        assert lib.sim_wide_walks() - wides == 1
+        H.assert_aov_equal(whole, staged, f"folded table, margin {margin}")
+        seen.append(lib.sim_order_redos())
+    assert seen[0] <= 2 and seen[1] > 50 and seen[2] > seen[1], seen
 
 
 def test_nearer_child_first_hands_back_what_depends_on_the_order():
