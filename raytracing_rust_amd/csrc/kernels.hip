@@ -479,7 +479,16 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   const uint32_t n = c->n_in;
   // a queue of n entries has no more than n / RT_SHADE_CHUNK + 1 chunks to hand out: workgroups beyond that leave before
   // staging anything (a launch over a nearly empty queue took 50 us for its 4096 workgroups to stage their tables)
-  if (blockIdx.x != 0 && (unsigned long long)blockIdx.x * RT_SHADE_CHUNK >= n) return;
+  // A short queue is handed out in smaller chunks, down to one entry per thread, so that it is spread over the whole
+  // GPU: with full chunks 60 000 entries keep 15 workgroups busy for 16 trips each, and a trip is one whole chain
+  // of dependent loads (the late iterations of a call are nothing but such latencies).
+  uint32_t chunk = RT_SHADE_CHUNK;
+  const uint32_t spread = gridDim.x >= 8u ? gridDim.x / 8u : 1u;   // two workgroups per CU (every workgroup stages the scene's small tables first)
+  if ((unsigned long long)spread * RT_SHADE_CHUNK > n) {
+    chunk = ((n + spread - 1u) / spread + 255u) & ~255u;
+    chunk = chunk < 256u ? 256u : (chunk > RT_SHADE_CHUNK ? RT_SHADE_CHUNK : chunk);
+  }
+  if (blockIdx.x != 0 && (unsigned long long)blockIdx.x * chunk >= n) return;
   uint32_t probes = 0, drops = 0, dead = 0;
   __shared__ uint32_t s_first, s_out_base;
   __shared__ uint32_t s_cnt[RT_SHADE_SLOTS * RT_SHADE_KEYS], s_key_base[RT_SHADE_KEYS + 1], s_sorted[RT_SHADE_CHUNK];
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   // the queue is handed out dynamically, one chunk at a time: the trip count is the same for every thread of a
   // workgroup, and no workgroup is left with a long static share at the end of the launch
   for (;;) {
-  if (threadIdx.x == 0) s_first = atomicAdd(&c->work_shade, RT_SHADE_CHUNK);
+  if (threadIdx.x == 0) s_first = atomicAdd(&c->work_shade, chunk);
   for (uint32_t k = threadIdx.x; k < RT_SHADE_KEYS * RT_SHADE_SLOTS; k += 256u) s_cnt[k] = 0;
   __syncthreads();
   const uint32_t first = s_first;
@@ -545,6 +554,8 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t c_kind[RT_SHADE_PER_THREAD], c_mat[RT_SHADE_PER_THREAD], c_db[RT_SHADE_PER_THREAD], c_px[RT_SHADE_PER_THREAD], c_sm[RT_SHADE_PER_THREAD];
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    c_kind[e] = 0u; c_px[e] = 0u; c_sm[e] = 0u; c_db[e] = 0u; c_mat[e] = 0u;
+    if (e * 256u >= chunk) continue;   // (the same for every thread of the launch)
     const uint32_t k = first + e * 256u + threadIdx.x, ks = k < n ? k : first;
     c_kind[e] = h.kind_idx[ks];
     const uint32_t* u = qin.u + ks;
@@ -552,6 +563,7 @@ RT_UNROLL
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    if (e * 256u >= chunk) continue;
     const uint32_t hkind = RTX_NODE_KIND(c_kind[e]), hidx = RTX_NODE_IDX(c_kind[e]);
     const uint32_t* mp = &S.materials[0].kind;   // a miss reads something harmless
     if (hkind == RTX_NODE_SPHERE) mp = &S.spheres[hidx].mat;
@@ -561,6 +573,7 @@ RT_UNROLL
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    if (e * 256u >= chunk) continue;
     const uint32_t hkind = RTX_NODE_KIND(c_kind[e]);
     const bool hit = hkind == RTX_NODE_SPHERE || hkind == RTX_NODE_QUAD || hkind == RTX_NODE_MEDIUM;
     const uint32_t cls = mat_class[hit ? c_mat[e] : 0u];
@@ -571,6 +584,7 @@ RT_UNROLL
   // contributes nothing (no emission) and is dropped here (drawn for every entry, without a branch: the draws overlap).
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
+    if (e * 256u >= chunk) continue;
     const uint32_t depth = c_db[e] >> 16;
     uint32_t skip = depth == 0u ? 1u : 0u;
     if (RT_SHADE_DROP) {
@@ -582,8 +596,11 @@ RT_UNROLL
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
     const uint32_t k = first + e * 256u + threadIdx.x;
-    const bool valid = k < n && c_db[e] == 0u;
-    if (k < n) { dead += c_db[e] == 1u ? 1u : 0u; drops += c_db[e] == 2u ? 1u : 0u; }
+    my_key[e] = 0xFFFFFFFFu; my_rank[e] = 0u;
+    if (e * 256u >= chunk) continue;               // entries past the chunk belong to another workgroup
+    const bool mine = k < n;
+    const bool valid = mine && c_db[e] == 0u;
+    if (mine) { dead += c_db[e] == 1u ? 1u : 0u; drops += c_db[e] == 2u ? 1u : 0u; }
     const uint32_t key = c_mat[e];
     // stable rank among the entries of this wave with the same key: one ballot per key present in the wave
     const uint32_t v = e * 4u + wave;
@@ -1116,6 +1133,8 @@ static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a mul
   return v;
 }
 
+__global__ void k_exp_reset_tail(WfCounters* c) { c->work_tail = 0; }
+
 // How one iteration of the wavefront loop is launched for a given scene and queue capacity: which sections are walked
 // as streams, what each traversal kernel stages in LDS, which instantiation serves the world program.
 struct WfPlan {
@@ -1275,6 +1294,10 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
       hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
     else
       hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), tb, tt, 0, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
+    if (getenv("RTX_EXP_DOUBLE_TAIL") && !P.stream_tail && P.tail_lds) {
+      hipLaunchKernelGGL(k_exp_reset_tail, dim3(1), dim3(1), 0, s, B.c);
+      hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
+    }
     if (timed_tail) span_end(ctx, s, st);
   }
   hipLaunchKernelGGL(k_wf_shade, dim3(P.shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, B.c, qin, B.hits, qout, accum_dev, ctx->d_counters, sc->mat_class);
@@ -1320,17 +1343,21 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const WfPlan P = wf_make_plan(sc, cap, per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes));
   const unsigned long long seed = (unsigned long long)o->seed;
 
-  struct Run { rtx_context::WfLane* L; hipStream_t s; WfFrame fr; int cur, k; bool done; };
+  struct Run { rtx_context::WfLane* L; hipStream_t s; WfFrame fr; int cur, k, iters, limit; bool done, closed; };
   Run runs[RT_WF_MAX_LANES];
   if (n_lanes > 1) HIP_TRY(ctx, hipEventRecord(ctx->wf_fork, stream));
   for (int l = 0; l < n_lanes; ++l) {
     Run& r = runs[l];
-    r.L = &ctx->wf[l]; r.s = l == 0 ? stream : r.L->stream; r.cur = 0; r.k = 0; r.done = false;
+    r.L = &ctx->wf[l]; r.s = l == 0 ? stream : r.L->stream; r.cur = 0; r.k = 0; r.done = false; r.iters = 0; r.closed = false;
     // sample indices of this pipeline: an equal share of the call's range
     const int sb = o->sample_begin + (int)((long long)n_samples * l / n_lanes), se = o->sample_begin + (int)((long long)n_samples * (l + 1) / n_lanes);
     r.fr.x0 = o->x0; r.fr.y0 = o->y0; r.fr.w = o->x1 - o->x0; r.fr.h = o->y1 - o->y0; r.fr.sample_begin = sb; r.fr.per_sample = (uint32_t)per_sample;
     // a path of depth 0 is black (camera.rs:169-171): nothing to trace
     const unsigned long long total = cam->max_depth > 0 ? per_sample * (unsigned long long)(se - sb) : 0ull;
+    // When the queue holds the pipeline's whole share, every camera path starts in the first iteration and none lives
+    // longer than max_depth bounces, plus one iteration that drops the last dead entries: no iteration beyond that is
+    // enqueued (a chunk of launches over empty queues is a quarter of a millisecond at the end of a small call).
+    r.limit = total <= (unsigned long long)cap ? cam->max_depth + 1 : 0x7FFFFFFF;
     if (l > 0) HIP_TRY(ctx, hipStreamWaitEvent(r.s, ctx->wf_fork, 0));
     hipLaunchKernelGGL(k_wf_begin, dim3(1), dim3(1), 0, r.s, r.L->c, total);
   }
@@ -1347,13 +1374,13 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
     for (int it = 0; it < chunk; ++it)
       for (int l = 0; l < n_lanes; ++l) {
         Run& r = runs[l];
-        if (r.done) continue;
+        if (r.done || r.closed || r.iters >= r.limit) continue;
         wf_launch_iteration(sc, P, cam, r.fr, seed, use_lights, *r.L, r.cur, r.s, accum_dev, timed_sections);
-        r.cur ^= 1;
+        r.cur ^= 1; r.iters += 1;
       }
     for (int l = 0; l < n_lanes; ++l) {
       Run& r = runs[l];
-      if (r.done) continue;
+      if (r.done || r.closed) continue;
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
       hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
@@ -1368,7 +1395,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       if (r.k > 0) {
         HIP_TRY(ctx, hipEventSynchronize(L.ev[(r.k - 1) & 1]));
         const WfCounters& c = L.host[(r.k - 1) & 1];
-        r.done = c.n_out == 0 && c.next_path == c.total_paths;
+        r.done = (c.n_out == 0 || c.finished != 0) && c.next_path == c.total_paths;   // finished: k_wf_finish ran the survivors to their end
         if (r.done) {  // the traversal launches of this pipeline, timed on the device
           ctx->traverse_ms += (double)c.k1_sum / ctx->wall_clock_khz;
           ctx->traverse_launches += c.k1_count;
@@ -1376,6 +1403,8 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
           ctx->shade_launches += c.sh_count;
         }
       }
+      if (r.closed && !r.done) { r.closed = false; r.limit = 0x7FFFFFFF; }   // (not expected: go on chunk by chunk)
+      else if (r.iters >= r.limit) r.closed = true;                          // only the counters of this chunk are still to come
       r.k += 1;
       if (!r.done) all_done = false;
       if (ctx->pending.size() > 2048) drain_events(ctx);
