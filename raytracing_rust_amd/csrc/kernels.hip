@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   __syncthreads();
   const uint32_t first = s_first;
   if (first >= n) break;
+  const uint32_t lim = first + chunk < n ? first + chunk : n;   // this trip's entries: [first, lim)
   RT_KPROF_T(kp_t0);
   uint32_t my_key[RT_SHADE_PER_THREAD], my_rank[RT_SHADE_PER_THREAD];
   // Keys of this thread's entries.  Every step is written as a loop of its own over the entries, with unconditional
@@ -554,16 +555,13 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_wf_shade(Scene S, rtx_cam
   uint32_t c_kind[RT_SHADE_PER_THREAD], c_mat[RT_SHADE_PER_THREAD], c_db[RT_SHADE_PER_THREAD], c_px[RT_SHADE_PER_THREAD], c_sm[RT_SHADE_PER_THREAD];
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
-    c_kind[e] = 0u; c_px[e] = 0u; c_sm[e] = 0u; c_db[e] = 0u; c_mat[e] = 0u;
-    if (e * 256u >= chunk) continue;   // (the same for every thread of the launch)
-    const uint32_t k = first + e * 256u + threadIdx.x, ks = k < n ? k : first;
+    const uint32_t k = first + e * 256u + threadIdx.x, ks = k < lim ? k : first;
     c_kind[e] = h.kind_idx[ks];
     const uint32_t* u = qin.u + ks;
     c_px[e] = u[0]; c_sm[e] = u[(size_t)cap]; c_db[e] = u[2 * (size_t)cap];
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
-    if (e * 256u >= chunk) continue;
     const uint32_t hkind = RTX_NODE_KIND(c_kind[e]), hidx = RTX_NODE_IDX(c_kind[e]);
     const uint32_t* mp = &S.materials[0].kind;   // a miss reads something harmless
     if (hkind == RTX_NODE_SPHERE) mp = &S.spheres[hidx].mat;
@@ -573,7 +571,6 @@ RT_UNROLL
   }
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
-    if (e * 256u >= chunk) continue;
     const uint32_t hkind = RTX_NODE_KIND(c_kind[e]);
     const bool hit = hkind == RTX_NODE_SPHERE || hkind == RTX_NODE_QUAD || hkind == RTX_NODE_MEDIUM;
     const uint32_t cls = mat_class[hit ? c_mat[e] : 0u];
@@ -584,7 +581,6 @@ RT_UNROLL
   // contributes nothing (no emission) and is dropped here (drawn for every entry, without a branch: the draws overlap).
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
-    if (e * 256u >= chunk) continue;
     const uint32_t depth = c_db[e] >> 16;
     uint32_t skip = depth == 0u ? 1u : 0u;
     if (RT_SHADE_DROP) {
@@ -596,11 +592,8 @@ RT_UNROLL
 RT_UNROLL
   for (uint32_t e = 0; e < RT_SHADE_PER_THREAD; ++e) {
     const uint32_t k = first + e * 256u + threadIdx.x;
-    my_key[e] = 0xFFFFFFFFu; my_rank[e] = 0u;
-    if (e * 256u >= chunk) continue;               // entries past the chunk belong to another workgroup
-    const bool mine = k < n;
-    const bool valid = mine && c_db[e] == 0u;
-    if (mine) { dead += c_db[e] == 1u ? 1u : 0u; drops += c_db[e] == 2u ? 1u : 0u; }
+    const bool valid = k < lim && c_db[e] == 0u;
+    if (k < lim) { dead += c_db[e] == 1u ? 1u : 0u; drops += c_db[e] == 2u ? 1u : 0u; }
     const uint32_t key = c_mat[e];
     // stable rank among the entries of this wave with the same key: one ballot per key present in the wave
     const uint32_t v = e * 4u + wave;
