@@ -51,10 +51,10 @@ OWN_TRAVERSE_BYTES, OWN_NEW_PATH_BYTES, OWN_BOUNCE_BYTES = 100, 108, 390
 # active per VALU instruction.
 PMC = {
     "profile": "profiles/r2_pmc_summary.txt (one step of 10 rows, 1.06996e9 segments, one pipeline)",
-    "valu_wave_instructions_per_segment": 72.7,
-    # (2 x FETCH_SIZE + WRITE_SIZE) / segments; FETCH_SIZE as reported would give 94.3 and 191.9
-    "traffic_bytes_per_segment": {"k_wf_traverse": 134.3, "k_wf_shade": 319.3, "k_wf_stream_head": 56.6, "k_wf_stream_deferred": 15.3},
-    "lanes_active": {"k_wf_traverse": 58.2, "k_wf_stream_head": 42.7, "k_wf_stream_deferred": 34.5, "k_wf_shade": 42.6},
+    "valu_wave_instructions_per_segment": 72.2,
+    # (2 x FETCH_SIZE + WRITE_SIZE) / segments; FETCH_SIZE as reported would give 96.6 and 196.4
+    "traffic_bytes_per_segment": {"k_wf_traverse": 137.5, "k_wf_shade": 327.0, "k_wf_stream_head": 58.0, "k_wf_stream_deferred": 15.7},
+    "lanes_active": {"k_wf_traverse": 56.4, "k_wf_stream_head": 41.9, "k_wf_stream_deferred": 34.6, "k_wf_shade": 40.4},
 }
 SIMDS, CLOCK_GHZ, F64_CYCLES_PER_WAVE_INSTRUCTION = 256 * 4, 2.4, 4   # vector f64: 16 lanes per clock per SIMD
 
