@@ -1126,8 +1126,6 @@ static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a mul
   return v;
 }
 
-__global__ void k_exp_reset_tail(WfCounters* c) { c->work_tail = 0; }
-
 // How one iteration of the wavefront loop is launched for a given scene and queue capacity: which sections are walked
 // as streams, what each traversal kernel stages in LDS, which instantiation serves the world program.
 struct WfPlan {
@@ -1287,10 +1285,6 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
       hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
     else
       hipLaunchKernelGGL((k_wf_traverse<false, true, MEDIA_NONE>), tb, tt, 0, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
-    if (getenv("RTX_EXP_DOUBLE_TAIL") && !P.stream_tail && P.tail_lds) {
-      hipLaunchKernelGGL(k_exp_reset_tail, dim3(1), dim3(1), 0, s, B.c);
-      hipLaunchKernelGGL((k_wf_traverse<true, true, MEDIA_NONE>), tb, tt, P.tail_bytes, s, dev, cap, seed, B.c, qin, B.hits, B.defer, ctx->d_counters, *cam, fr);
-    }
     if (timed_tail) span_end(ctx, s, st);
   }
   hipLaunchKernelGGL(k_wf_shade, dim3(P.shade_blocks), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, B.c, qin, B.hits, qout, accum_dev, ctx->d_counters, sc->mat_class);

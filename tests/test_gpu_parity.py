@@ -333,6 +333,33 @@ def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
     scene.close()
 
 
+@pytest.mark.parametrize("wide,top", [(None, None), ("0", None), ("0", "0")], ids=["folded-table", "lds-top", "program-records"])
+def test_head_section_in_global_memory_walks_trace_the_same_paths(gpu_ctx, monkeypatch, wide, top):
+    """A head section too large for LDS (the stress scene's BVH) is walked from global memory over the table that
+    folds two levels of its tree into one record (the default), or box by box over the program's own records with the
+    first levels of the tree in an LDS table (RTX_WF_WIDE=0) or without it (RTX_WF_TOP=0 as well).  All of them, at
+    several queue capacities, must trace the fused pipeline's paths, which walks the program in the reference's order."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("stress", gp, width=320, spp=4, depth=12, n_prims=200000)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=93, pipeline=_capi.PIPELINE_FUSED))
+    sa = gpu_ctx.stats()
+    if wide is not None:
+        monkeypatch.setenv("RTX_WF_WIDE", wide)
+    if top is not None:
+        monkeypatch.setenv("RTX_WF_TOP", top)
+    for cap in ("65536", "16384"):
+        monkeypatch.setenv("RTX_WF_CAPACITY", cap)
+        gpu_ctx.reset_stats()
+        b = scene.render(cam, rt.render_opts(cam, seed=93, pipeline=_capi.PIPELINE_WAVEFRONT))
+        sb = gpu_ctx.stats()
+        assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"] and sb["head_launches"] > 0
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    assert a.sum() > 0
+    scene.close()
+
+
 @pytest.mark.parametrize("name,kw,near", [("final", dict(width=240, spp=16, depth=30), "2"),
                                           ("stress", dict(width=320, spp=4, depth=12, n_prims=200000), "1")])
 def test_rays_handed_back_by_the_nearer_child_first_walk_change_nothing(gpu_ctx, monkeypatch, name, kw, near):
