@@ -200,15 +200,19 @@ struct CompiledProgram {
     head_top_units = (uint32_t)units.size() - head_top_begin;
   }
   // The box tree of such a head section with two levels folded into one, appended to the image for the walk from
-  // global memory (walk_stream_wide): a record of PROG_WIDE_UNITS units (256 bytes, 256-byte aligned) per box that has
-  // two box children, holding the boxes of its (up to four) grandchildren, or of a child itself where that child is a
-  // leaf, in the program's order, each with a descriptor: the record of the slot's own box when that has box children
-  // (low word, high word 0), or where its leaf units begin and end in the program (low and high word; the end is
+  // global memory (walk_stream_wide): a record of PROG_WIDE_UNITS units (128 bytes, 128-byte aligned: one cache line)
+  // per box that has two box children, holding the boxes of its (up to four) grandchildren, or of a child itself where
+  // that child is a leaf, in the program's order: 24 floats (lo[3], hi[3] per slot, each bound rounded OUTWARD from the
+  // program's double), then a descriptor per slot: the record of the slot's own box when that has box children (low
+  // word, high word 0), or the unit position behind the box of a leaf slot (low word; high word: where its units end,
   // never 0), or PROG_WIDE_EMPTY.  Records lie in depth-first order like the program (a subtree is one stretch of
-  // memory); record 0 belongs to the section's root box.  A box test that is skipped this way (a child with box
-  // children) cannot change what the walk finds: a box contains its children's boxes exactly (aabb.rs:38-45 takes
-  // minima and maxima) and every operation of Aabb::hit is monotone in the bounds, so a ray that passes a box passes
-  // every box around it for the same interval.
+  // memory); record 0 belongs to the section's root box.
+  // The table only CULLS: a ray that passes a box of the program passes the wider box here (every operation of
+  // Aabb::hit, aabb.rs:132-167, is monotone in the bounds), and it passes every box around it (a box contains its
+  // children's boxes exactly: aabb.rs:38-45 takes minima and maxima), so leaving the boxes in between untested loses
+  // nothing.  Whether a leaf's units are tested is decided by the program's own box record in front of them.
+  static float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
+  static float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
   void build_head_wide() {
     head_wide_begin = 0; head_wide_nodes = 0; head_wide_depth = 0;
     uint32_t depth = 0;
@@ -221,7 +225,7 @@ struct CompiledProgram {
     // emits the record of inner box p (and, behind it, the records of its inner slots); returns its index
     std::function<uint32_t(uint32_t, int)> emit = [&](uint32_t p, int level) -> uint32_t {
       const uint32_t me = (uint32_t)(table.size() / PROG_WIDE_UNITS);
-      if (level > 40 || me >= (1u << 27)) { ok = false; return 0u; }
+      if (level > 40 || me >= (1u << 30)) { ok = false; return 0u; }
       depth = std::max(depth, (uint32_t)level + 1u);
       table.insert(table.end(), PROG_WIDE_UNITS, 0ull);
       uint32_t slots[4], n = 0;
@@ -234,17 +238,22 @@ struct CompiledProgram {
         uint64_t desc = PROG_WIDE_EMPTY;
         if (k < n) {
           const uint32_t q = slots[k];
-          for (uint32_t j = 0; j < 6; ++j) table[(size_t)me * PROG_WIDE_UNITS + 6 * k + j] = units[q + 1 + j];
+          float f[6];
+          for (uint32_t j = 0; j < 6; ++j) {
+            double v; memcpy(&v, &units[q + 1 + j], 8);
+            f[j] = j < 3 ? round_down(v) : round_up(v);
+          }
+          memcpy((char*)(table.data() + (size_t)me * PROG_WIDE_UNITS) + 24u * k, f, 24);
           if (inner(q)) desc = (uint64_t)emit(q, level + 1);
           else desc = (uint64_t)(q + PROG_BOX_UNITS) | ((units[q] >> 32) << 32);
         }
-        table[(size_t)me * PROG_WIDE_UNITS + 24 + k] = desc;
+        table[(size_t)me * PROG_WIDE_UNITS + 12 + k] = desc;
       }
       return me;
     };
     emit(world_begin, 0);
-    while (units.size() & 31u) units.push_back(nop());
-    if (!ok || units.size() + table.size() + 64u >= (1ull << 32)) return;
+    while (units.size() & 15u) units.push_back(nop());
+    if (!ok || units.size() + table.size() + 64u >= (1ull << 31)) return;   // unit positions of leaves go on the stack with a flag bit
     head_wide_begin = (uint32_t)units.size(); head_wide_nodes = (uint32_t)(table.size() / PROG_WIDE_UNITS); head_wide_depth = depth;
     units.insert(units.end(), table.begin(), table.end());
   }

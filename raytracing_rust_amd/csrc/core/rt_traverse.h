@@ -77,10 +77,10 @@ struct Scene : rtx_scene_desc {
   uint32_t head_top_begin, head_top_nodes, head_top_units;
   // The head section's box tree with two levels folded into one (CompiledProgram::build_head_wide), for the walk of a
   // section that stays in global memory: head_wide_nodes records of PROG_WIDE_UNITS units from unit head_wide_begin
-  // (a multiple of 32: records are 256-byte aligned), the root's children first.  0 nodes = none.
+  // (a multiple of 16: records are 128-byte aligned), the root's children first.  0 nodes = none.
   uint32_t head_wide_begin, head_wide_nodes, head_wide_depth;   // depth: records on the longest way down
 };
-#define PROG_WIDE_UNITS 32u                // four boxes (6 units each), four slot descriptors, four spare units
+#define PROG_WIDE_UNITS 16u                // four boxes (6 floats each, rounded outward), four slot descriptors
 #define PROG_WIDE_EMPTY 0xFFFFFFFFFFFFFFFFull   // slot descriptor: no box in this slot
 // record sizes in units (header included)
 #define PROG_BOX_UNITS 7u        // header, lo[3], hi[3]
@@ -292,20 +292,22 @@ RT_HD bool sphere_rec_hit_t(const double* rec, const V3& o, const V3& d, double 
 }
 
 // Quad::hit, quad.rs:66-86 (plane test, interval, interior test).
-RT_HD bool quad_hit_t(const rtx_quad& q, const V3& o, const V3& d, double tmin, double tmax, double& t) {
-  V3 n = v3(q.normal);
+RT_HD bool quad_hit_v(const V3& n, double qd, const V3& qq, const V3& w, const V3& qu, const V3& qv, const V3& o, const V3& d,
+                      double tmin, double tmax, double& t) {   // the quad's fields as values (a record held in registers)
   double denom = dot(n, d);
   if (fabs(denom) < 1e-8) return false;
-  double tt = (q.d - dot(n, o)) / denom;
+  double tt = (qd - dot(n, o)) / denom;
   if (!(tmin <= tt && tt <= tmax)) return false;
   V3 p = ray_at(o, d, tt);
-  V3 planar = p - v3(q.q);
-  V3 w = v3(q.w);
-  double a = dot(w, cross(planar, v3(q.v)));
-  double b = dot(w, cross(v3(q.u), planar));
+  V3 planar = p - qq;
+  double a = dot(w, cross(planar, qv));
+  double b = dot(w, cross(qu, planar));
   if (!(0.0 <= a && a <= 1.0) || !(0.0 <= b && b <= 1.0)) return false;
   t = tt;
   return true;
+}
+RT_HD bool quad_hit_t(const rtx_quad& q, const V3& o, const V3& d, double tmin, double tmax, double& t) {
+  return quad_hit_v(v3(q.normal), q.d, v3(q.q), v3(q.w), v3(q.u), v3(q.v), o, d, tmin, tmax, t);
 }
 // Sphere::hit for a static sphere from its compact record: centre = c0 + 0*time = c0 (sphere.rs:84-104).
 RT_HD bool sphere_s_hit_t(const DSphere& s, const V3& o, const V3& d, double tmin, double tmax, double& t) {
@@ -1123,43 +1125,141 @@ RT_UNROLL
   }
 }
 
+// Aabb::hit (slab_hit_entry: same operations, same decision) on bounds held in registers.
+RT_HD bool slab_hit_entry_v(double lx, double ly, double lz, double hx, double hy, double hz, const LRay& r, double tmin, double tmax, double& entry) {
+  const bool px = r.inv.x >= 0.0, py = r.inv.y >= 0.0, pz = r.inv.z >= 0.0;
+  const double bnx = px ? lx : hx, bfx = px ? hx : lx, bny = py ? ly : hy, bfy = py ? hy : ly, bnz = pz ? lz : hz, bfz = pz ? hz : lz;
+  double nrx = (bnx - r.o.x) * r.inv.x, frx = (bfx - r.o.x) * r.inv.x;
+  double nry = (bny - r.o.y) * r.inv.y, fry = (bfy - r.o.y) * r.inv.y;
+  double nrz = (bnz - r.o.z) * r.inv.z, frz = (bfz - r.o.z) * r.inv.z;
+  if (r.skip & 7u) {
+    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
+    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
+    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
+  }
+  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
+  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
+  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
+  entry = tmin;
+  return !(tmax <= tmin);
+}
+RT_HD double unit_f64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+RT_HD double unit_f32(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return (double)f; }
+struct alignas(16) UnitPair { uint64_t x, y; };
+
 // walk_stream_near for a head section that stays in global memory, over the table that folds two levels of its box
-// tree into one record (Scene::head_wide_*, CompiledProgram::build_head_wide): a lane reads the (up to) four boxes of
-// a record at once, 256 bytes at one address, tests them all, goes on with the nearest one that passes and leaves the
-// others on its stack, farthest first.  The tree is walked in half as many dependent memory round trips as box by box,
-// which is what bounds a walk whose every level is a cache miss.  Leaves are the program's: a leaf slot says where its
-// units lie, they are tested as in walk_stream_near (same classes, same tie rules by program position, same watch:
-// a candidate hit that does not lie behind the entry of its leaf's box by more than the margin marks the ray).
-// A marked ray, and any ray that is not finite, is walked again by its lane alone over the PROGRAM in the reference's
-// order (bvh.rs:94-102) with the exact bound, which is what is committed for it.
+// tree into one record (Scene::head_wide_*, CompiledProgram::build_head_wide).  Every step of a lane is one read of
+// 128 bytes at an address the lane knows, and EVERY lane of the wave takes its step in every trip of the loop: first
+// all lanes issue their reads, then each kind of step is computed for the lanes that are on it.  A walk whose every
+// step is a cache miss is bound by round trips to memory, and this way a round trip serves the whole wave instead of
+// the lanes of one kind of step.  The steps:
+//   record   the four boxes of a table record (floats, rounded outward: the table only culls) are tested together;
+//            the lane goes on with the nearest slot that passes and leaves the others on its stack, farthest first.
+//            The tree is walked in half as many dependent reads as box by box.
+//   leaf     the program's box record in front of a leaf's units and the units behind it, in one read: the box is
+//            tested as the reference tests it (same doubles, Aabb::hit, with the bound of that moment), sphere records
+//            are tested from the registers, general quads are noted (two at most; whatever else a leaf holds is
+//            tested record by record from memory as walk_stream_near does).
+//   quad     a noted quad's record from the scene's table.
+// Hits are compared as in walk_stream_near (tie rules by program position, so the order of the tests is free), with
+// the same watch: a candidate hit that does not lie behind the entry of its leaf's box by more than the margin marks
+// the ray.  A marked ray, and any ray that is not finite, is walked again by its lane alone over the PROGRAM in the
+// reference's order (bvh.rs:94-102) with the exact bound, which is what is committed for it.
 //   stk: per-lane stack (lane-private, stk[level * stk_stride]), 3 entries per level of the table
-//        (Scene::head_wide_depth); an entry is the record of a slot with box children, or 0x80000000 | record << 2 |
-//        slot for a leaf slot, whose box is tested again (with the bound of that moment) when the entry is taken.
+//        (Scene::head_wide_depth); an entry is the record of a slot with box children, or 0x80000000 | the unit
+//        position of a leaf slot's units.
 //   begin: the section's root box in the program (tested first, alone); wide: the table.
+// What a walk knows of its closest hit so far, for the record-by-record walk below.
+struct WideBest {
+  double tmax, leaf_entry;
+  uint32_t hit_kind, best_pos;
+  bool best_quad, suspect, fixed_mode;
+};
+// Records [p, end) of the program tested one after the other from memory, in the program's order, boxes included (a box
+// that fails is skipped with everything behind it, bvh.rs:94-102); stops at the end of a program or section.  The slow
+// path of walk_stream_wide: the records of a leaf its reads do not cover, and the whole section for a ray that is
+// walked again in the reference's order (fixed_mode: no watch).  Kept out of line: the registers its record kinds
+// need would otherwise be charged to the loop that calls it once in a while (RT_NOINLINE; measured slower out of line:
+// the call's register saves outweigh the gain, so it is inlined by default).
+#ifndef RT_NOINLINE
+#define RT_NOINLINE
+#endif
+template <bool QUADS>
+RT_HD RT_NOINLINE WideBest wide_walk_records(const uint64_t* prog, const rtx_quad* quads, double margin, LRay lr, WideBest b, uint32_t p, uint32_t end) {
+  const double tmin = 0.001;
+  auto wins = [&](double t, uint32_t pos, bool quad) {   // as in walk_stream_near
+    if (!b.fixed_mode && t <= b.leaf_entry + fabs(b.leaf_entry) * margin) b.suspect = true;
+    if (t < b.tmax) return true;
+    if (!(t == b.tmax)) return false;
+    if (!QUADS) return !b.best_quad && pos < b.best_pos;
+    if (quad != b.best_quad) return quad;
+    return quad ? pos > b.best_pos : pos < b.best_pos;
+  };
+  auto take_hit = [&](double t, uint32_t kind_idx, uint32_t pos, bool quad) { b.tmax = t; b.hit_kind = kind_idx; b.best_pos = pos; b.best_quad = quad; };
+  while (p < end) {
+    const uint64_t u = prog[p];
+    const uint32_t kind = RTX_NODE_KIND((uint32_t)u), idx = RTX_NODE_IDX((uint32_t)u), count = (uint32_t)(u >> 32);
+    double t;
+    if (kind == PROG_NODE_END || kind == PROG_NODE_SYNC) break;
+    if (kind == RTX_NODE_BOX) {
+      p = slab_hit((const double*)(prog + p + 1), lr, tmin, b.tmax) ? p + PROG_BOX_UNITS : count;
+    } else if (kind == PROG_NODE_SPHERE_S) {
+      for (uint32_t k = 0; k < count; ++k) {
+        const DSphere sph = *(const DSphere*)(prog + p + 1 + PROG_SPHERE_S_UNITS * k);
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, b.tmax, t) && wins(t, pos, false)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k), pos, false);
+      }
+      p += 1u + PROG_SPHERE_S_UNITS * count;
+    } else if (QUADS && (kind == RTX_NODE_QUAD || ((lr.skip & 8u) && (kind == PROG_NODE_QUAD_AA || kind == PROG_NODE_BOX6)))) {
+      uint32_t cnt = 1u, size = 1u;
+      if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
+      else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
+      for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (quad_hit_t(quads[idx + k], lr.o, lr.d, tmin, b.tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
+      }
+      p += size;
+    } else if (QUADS && kind == PROG_NODE_BOX6) {
+      const DBox6 bx = *(const DBox6*)(prog + p + 1);
+      for (int f = 0; f < 6; ++f) {
+        const uint32_t pos = (p << 6) + (uint32_t)f + 1u;
+        if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, b.tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f), pos, true);
+      }
+      p += PROG_BOX6_UNITS;
+    } else if (QUADS && kind == PROG_NODE_QUAD_AA) {
+      for (uint32_t k = 0; k < count; ++k) {
+        const DAAQuad qa = *(const DAAQuad*)(prog + p + 1 + PROG_QUAD_AA_UNITS * k);
+        const uint32_t pos = (p << 6) + k + 1u;
+        if (aaquad_hit_t(qa, lr.o, lr.d, tmin, b.tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
+      }
+      p += 1u + PROG_QUAD_AA_UNITS * count;
+    } else {
+      p += prog_record_units(u);
+    }
+  }
+  return b;
+}
+
 #ifndef RT_WIDE_REFILL
-#define RT_WIDE_REFILL RT_NEAR_REFILL
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WIDE_REFILL 16   // lanes out of work at which the wave takes new rays
+#else
+#define RT_WIDE_REFILL 1
 #endif
-#ifndef RT_WIDE_LEAF_BIAS
-#define RT_WIDE_LEAF_BIAS RT_NEAR_LEAF_BIAS_FAR
-#endif
-#ifndef RT_WIDE_LEAF_BIAS_DEN
-#define RT_WIDE_LEAF_BIAS_DEN RT_NEAR_LEAF_BIAS_FAR_DEN
 #endif
 template <bool QUADS, class Feed>
 RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin, Feed& feed, uint32_t* stk, uint32_t stk_stride, const uint64_t* wide) {
-  enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_QUAD = 4, CL_BOX6 = 7, CL_NODE = 8, CL_DONE = 10 };
-  enum { ST_NODE = 0, ST_SLOT = 1, ST_LEAF = 2, ST_POP = 3 };
-  const int bias = RT_WIDE_LEAF_BIAS, bias_den = RT_WIDE_LEAF_BIAS_DEN;
+  enum { ST_NODE = 0, ST_LEAF = 1, ST_QUAD = 2, ST_POP = 3 };
   const double tmin = 0.001;
-  bool have = false, best_quad = false, suspect = false, fixed_mode = false;
+  bool have = false, best_quad = false, suspect = false;
   double leaf_entry = -RT_INF, tmax_hi = RT_INF, tmax = RT_INF;
-  uint32_t id = 0, st = ST_POP, node = 0, slot = 0, i = begin, end = 0, sp = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
-  uint64_t unit = (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
+  uint32_t id = 0, st = ST_POP, node = 0, i = begin, sp = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
+  uint32_t nq = 0, qa_idx = 0, qa_pos = 0, qb_idx = 0, qb_pos = 0;   // quads of the current leaf still to test
   auto rs = feed.ray(0);
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
   auto wins = [&](double t, uint32_t pos, bool quad) {   // as in walk_stream_near
-    if (!fixed_mode && t <= leaf_entry + fabs(leaf_entry) * S.near_margin) suspect = true;
+    if (t <= leaf_entry + fabs(leaf_entry) * S.near_margin) suspect = true;
     if (t < tmax) return true;
     if (!(t == tmax)) return false;
     if (!QUADS) return !best_quad && pos < best_pos;
@@ -1169,67 +1269,37 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
   auto take_hit = [&](double t, uint32_t kind_idx, uint32_t pos, bool quad) {
     tmax = t; tmax_hi = t + t * S.near_margin; hit_kind = kind_idx; hit_ctx = 0; best_pos = pos; best_quad = quad;
   };
-  // one leaf record at unit p, every primitive of it (any class); returns the record's size in units
-  auto leaf_record = [&](uint32_t p, uint64_t u) -> uint32_t {
-    const uint32_t kind = RTX_NODE_KIND((uint32_t)u), idx = RTX_NODE_IDX((uint32_t)u), count = (uint32_t)(u >> 32);
+  auto sphere_v = [&](uint64_t cx, uint64_t cy, uint64_t cz, uint64_t r, uint32_t idx, uint32_t pos) {
+    DSphere sph; sph.cx = unit_f64(cx); sph.cy = unit_f64(cy); sph.cz = unit_f64(cz); sph.r = unit_f64(r);
     double t;
-    if (kind == PROG_NODE_SPHERE_S) {
-      for (uint32_t k = 0; k < count; ++k) {
-        const DSphere sph = *(const DSphere*)(prog + p + 1 + PROG_SPHERE_S_UNITS * k);
-        const uint32_t pos = (p << 6) + k + 1u;
-        if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, false)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k), pos, false);
-      }
-      return 1u + PROG_SPHERE_S_UNITS * count;
-    }
-    if (QUADS && (kind == RTX_NODE_QUAD || ((lr.skip & 8u) && (kind == PROG_NODE_QUAD_AA || kind == PROG_NODE_BOX6)))) {
-      uint32_t cnt = 1u, size = 1u;
-      if (kind == PROG_NODE_QUAD_AA) { cnt = count; size = 1u + PROG_QUAD_AA_UNITS * count; }
-      else if (kind == PROG_NODE_BOX6) { cnt = 6u; size = PROG_BOX6_UNITS; }
-      for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t pos = (p << 6) + k + 1u;
-        if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
-      }
-      return size;
-    }
-    if (QUADS && kind == PROG_NODE_BOX6) {
-      const DBox6 bx = *(const DBox6*)(prog + p + 1);
-      for (int f = 0; f < 6; ++f) {
-        const uint32_t pos = (p << 6) + (uint32_t)f + 1u;
-        if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f), pos, true);
-      }
-      return PROG_BOX6_UNITS;
-    }
-    if (QUADS && kind == PROG_NODE_QUAD_AA) {
-      for (uint32_t k = 0; k < count; ++k) {
-        const DAAQuad qa = *(const DAAQuad*)(prog + p + 1 + PROG_QUAD_AA_UNITS * k);
-        const uint32_t pos = (p << 6) + k + 1u;
-        if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k), pos, true);
-      }
-      return 1u + PROG_QUAD_AA_UNITS * count;
-    }
-    return prog_record_units(u);
+    if (sphere_s_hit_t_incl(sph, lr.o, lr.d, tmin, tmax, t) && wins(t, pos, false)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_SPHERE, idx), pos, false);
+  };
+  // records [p, end) from memory, out of line
+  auto records = [&](uint32_t p, uint32_t end, bool fixed) {
+    WideBest b;
+    b.tmax = tmax; b.leaf_entry = leaf_entry; b.hit_kind = hit_kind; b.best_pos = best_pos; b.best_quad = best_quad; b.suspect = suspect; b.fixed_mode = fixed;
+    b = wide_walk_records<QUADS>(prog, S.quads, S.near_margin, lr, b, p, end);
+    tmax = b.tmax; tmax_hi = b.tmax + b.tmax * S.near_margin; hit_kind = b.hit_kind; best_pos = b.best_pos; best_quad = b.best_quad; suspect = b.suspect;
+  };
+  auto note_quad = [&](uint32_t idx, uint32_t pos) {
+    if (nq == 0) { qa_idx = idx; qa_pos = pos; } else { qb_idx = idx; qb_pos = pos; }
+    nq += 1;
   };
   for (;;) {
-    if (have && (st == ST_POP || (st == ST_LEAF && i >= end))) {   // out of units: the nearest box left behind, or hand in
+    if (have && st == ST_POP) {   // nothing left where the lane stood: the nearest box left behind, or hand in
       if (sp == 0) {
         if (suspect) {   // once more over the program, this lane alone, in the reference's order
           feed.note_redo();
           feed.start(id, tmax, hit_kind, hit_ctx);
-          fixed_mode = true; suspect = false; best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
-          for (uint32_t p = begin;;) {
-            const uint64_t u = prog[p];
-            const uint32_t k = RTX_NODE_KIND((uint32_t)u);
-            if (k == PROG_NODE_END || k == PROG_NODE_SYNC) break;
-            if (k == RTX_NODE_BOX) p = slab_hit((const double*)(prog + p + 1), lr, tmin, tmax) ? p + PROG_BOX_UNITS : (uint32_t)(u >> 32);
-            else p += leaf_record(p, u);
-          }
-          fixed_mode = false;
+          best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
+          records(begin, 0xFFFFFFFFu, true);
+          suspect = false;
         }
         feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
       } else {
         sp -= 1;
         const uint32_t e = stk[sp * stk_stride];
-        if (e & 0x80000000u) { node = (e & 0x7FFFFFFFu) >> 2; slot = e & 3u; st = ST_SLOT; }
+        if (e & 0x80000000u) { i = e & 0x7FFFFFFFu; st = ST_LEAF; }
         else { node = e; st = ST_NODE; }
       }
     }
@@ -1239,7 +1309,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         id = nid; rs = feed.ray(id);
         feed.start(id, tmax, hit_kind, hit_ctx); tmax_hi = tmax + tmax * S.near_margin;
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
-        have = true; sp = 0; suspect = (lr.skip & 8u) != 0u; fixed_mode = false; leaf_entry = -RT_INF;
+        have = true; sp = 0; nq = 0; suspect = (lr.skip & 8u) != 0u; leaf_entry = -RT_INF;
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
         // the root box, alone; its children are the table's first record
         node = 0; st = (!suspect && slab_hit((const double*)(prog + begin + 1), lr, tmin, tmax_hi)) ? ST_NODE : ST_POP;
@@ -1249,90 +1319,105 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
       if (feed.more()) continue;
       break;
     }
-    const uint32_t kind = RTX_NODE_KIND((uint32_t)unit);
-    int cls = CL_CHEAP;
-    if (!have || st == ST_POP || (st == ST_LEAF && i >= end)) cls = CL_DONE;
-    else if (st != ST_LEAF) cls = CL_NODE;
-    else if (kind == PROG_NODE_SPHERE_S) cls = CL_SPHERE_S;
-    else if (QUADS && kind == PROG_NODE_BOX6) cls = (lr.skip & 8u) ? CL_QUAD : CL_BOX6;
-    else if (QUADS && kind == PROG_NODE_QUAD_AA) cls = (lr.skip & 8u) ? CL_QUAD : CL_QUAD_AA;
-    else if (QUADS && kind == RTX_NODE_QUAD) cls = CL_QUAD;
-    if (RT_WAVE_ANY(cls == CL_CHEAP)) {
-      if (cls == CL_CHEAP) {   // fillers, and the guard box in front of a BOX6 record: on to the record, or past it
-        if (kind == RTX_NODE_BOX) i = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax) ? i + PROG_BOX_UNITS : (uint32_t)(unit >> 32);
-        else i += prog_record_units(unit);
-        unit = prog[i < end ? i : begin];
-      }
-      continue;
+    // every lane's read: 16 units, at 16-byte granularity from the table of records or of quads, or of the program
+    // from the box record in front of a leaf's units on
+    const bool on_node = have && st == ST_NODE, on_leaf = have && st == ST_LEAF, on_quad = QUADS && have && st == ST_QUAD;
+    uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
+RT_UNROLL
+    for (int k = 0; k < 16; ++k) blob[k] = 0ull;
+    if (on_node || on_quad) {
+      const UnitPair* src = on_node ? (const UnitPair*)(wide + (size_t)node * PROG_WIDE_UNITS) : (const UnitPair*)(S.quads + qa_idx);
+RT_UNROLL
+      for (int k = 0; k < 8; ++k) { const UnitPair v = src[k]; blob[2 * k] = v.x; blob[2 * k + 1] = v.y; }
+    } else if (on_leaf) {
+      const uint64_t* src = prog + (i - PROG_BOX_UNITS);
+RT_UNROLL
+      for (int k = 0; k < 16; ++k) blob[k] = src[k];
+      blob16 = src[16];
     }
-    const int n_x = RT_WAVE_COUNT(cls == CL_NODE), n_ss = RT_WAVE_COUNT(cls == CL_SPHERE_S);
-    const int n_b = QUADS ? RT_WAVE_COUNT(cls == CL_BOX6) : 0, n_a = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD_AA) : 0, n_q = QUADS ? RT_WAVE_COUNT(cls == CL_QUAD) : 0;
-    const int n_leaf = n_ss + n_b + n_a + n_q;
-    if (n_leaf == 0 && n_x == 0) continue;   // only lanes that hand in or take from their stacks
-    if (n_x > 0 && (n_leaf == 0 || n_x * bias >= n_leaf * bias_den)) {
-      bool on_node = cls == CL_NODE;
-      int nb, ns, nd;
-      do {
-        if (on_node) {
-          const uint64_t* nd_ = wide + (size_t)node * PROG_WIDE_UNITS;
-          if (st == ST_SLOT) {   // a leaf slot taken from the stack: its box once more, with the bound of now
-            double e;
-            const uint64_t dsc = nd_[24u + slot];
-            if (slab_hit_entry((const double*)(nd_ + 6u * slot), lr, tmin, tmax_hi, e)) {
-              leaf_entry = e; i = (uint32_t)dsc; end = (uint32_t)(dsc >> 32); unit = prog[i]; st = ST_LEAF;
-            } else st = ST_POP;
-          } else {
-            double e0 = RT_INF, e1 = RT_INF, e2 = RT_INF, e3 = RT_INF;
-            const uint64_t d0 = nd_[24], d1 = nd_[25], d2 = nd_[26], d3 = nd_[27];
-            if (!(d0 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_), lr, tmin, tmax_hi, e0))) e0 = RT_INF;
-            if (!(d1 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 6), lr, tmin, tmax_hi, e1))) e1 = RT_INF;
-            if (!(d2 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 12), lr, tmin, tmax_hi, e2))) e2 = RT_INF;
-            if (!(d3 != PROG_WIDE_EMPTY && slab_hit_entry((const double*)(nd_ + 18), lr, tmin, tmax_hi, e3))) e3 = RT_INF;
-            // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
-            // (an entry is finite: the bound it was tested against is)
-            uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
+    if (RT_WAVE_ANY(on_node)) {
+      if (on_node) {
+        double e0 = RT_INF, e1 = RT_INF, e2 = RT_INF, e3 = RT_INF;
+        const uint64_t d0 = blob[12], d1 = blob[13], d2 = blob[14], d3 = blob[15];
+        if (!(d0 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[0], 0), unit_f32(blob[0], 1), unit_f32(blob[1], 0), unit_f32(blob[1], 1), unit_f32(blob[2], 0), unit_f32(blob[2], 1), lr, tmin, tmax_hi, e0))) e0 = RT_INF;
+        if (!(d1 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[3], 0), unit_f32(blob[3], 1), unit_f32(blob[4], 0), unit_f32(blob[4], 1), unit_f32(blob[5], 0), unit_f32(blob[5], 1), lr, tmin, tmax_hi, e1))) e1 = RT_INF;
+        if (!(d2 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[6], 0), unit_f32(blob[6], 1), unit_f32(blob[7], 0), unit_f32(blob[7], 1), unit_f32(blob[8], 0), unit_f32(blob[8], 1), lr, tmin, tmax_hi, e2))) e2 = RT_INF;
+        if (!(d3 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[9], 0), unit_f32(blob[9], 1), unit_f32(blob[10], 0), unit_f32(blob[10], 1), unit_f32(blob[11], 0), unit_f32(blob[11], 1), lr, tmin, tmax_hi, e3))) e3 = RT_INF;
+        // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
+        // (an entry is finite: the lower bound it starts from is)
+        uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
 #define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const double te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
-            RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)
+        RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)
 #undef RT_WIDE_CE
-            auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
-            auto push = [&](uint32_t k) {
-              const uint64_t dsc = desc_of(k);
-              stk[sp * stk_stride] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (node << 2) | k);
-              sp += 1;
-            };
-            if (e3 < RT_INF) push(k3);
-            if (e2 < RT_INF) push(k2);
-            if (e1 < RT_INF) push(k1);
-            if (e0 < RT_INF) {
-              const uint64_t dsc = desc_of(k0);
-              if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
-              else { leaf_entry = e0; i = (uint32_t)dsc; end = (uint32_t)(dsc >> 32); unit = prog[i]; st = ST_LEAF; }
-            } else st = ST_POP;
-          }
-          if (st == ST_POP && sp > 0) {   // nothing here: on to the nearest box left behind
-            sp -= 1;
-            const uint32_t e = stk[sp * stk_stride];
-            if (e & 0x80000000u) { node = (e & 0x7FFFFFFFu) >> 2; slot = e & 3u; st = ST_SLOT; }
-            else { node = e; st = ST_NODE; }
-          }
-          RT_TRACE_STEP(RTX_NODE_BOX);
-        }
-        const bool fin = !have || st == ST_POP || (st == ST_LEAF && i >= end);
-        on_node = !fin && st != ST_LEAF;
-        nb = RT_WAVE_COUNT(on_node); nd = RT_WAVE_COUNT(fin);
-        ns = RT_WAVE_LANES - nb - nd;
-      } while (nb > 0 && (ns == 0 || nb * bias >= ns * bias_den) && !(nd >= RT_WIDE_REFILL));
-      continue;
+        auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
+        auto push = [&](uint32_t k) {
+          const uint64_t dsc = desc_of(k);
+          stk[sp * stk_stride] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc);
+          sp += 1;
+        };
+        if (e3 < RT_INF) push(k3);
+        if (e2 < RT_INF) push(k2);
+        if (e1 < RT_INF) push(k1);
+        if (e0 < RT_INF) {
+          const uint64_t dsc = desc_of(k0);
+          if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
+          else { i = (uint32_t)dsc; st = ST_LEAF; }
+        } else st = ST_POP;
+        RT_TRACE_STEP(RTX_NODE_BOX);
+      }
     }
-    // leaves: the class most lanes wait for
-    int pick = CL_SPHERE_S, best_n = n_ss;
-    if (QUADS && n_b > best_n) { pick = CL_BOX6; best_n = n_b; }
-    if (QUADS && n_a > best_n) { pick = CL_QUAD_AA; best_n = n_a; }
-    if (QUADS && n_q > best_n) { pick = CL_QUAD; best_n = n_q; }
-    if (cls == pick) {
-      i += leaf_record(i, unit);
-      RT_TRACE_STEP(32u + (uint32_t)pick);
-      unit = prog[i < end ? i : begin];
+    uint32_t rest_p = 0, rest_end = 0;
+    if (RT_WAVE_ANY(on_leaf)) {
+      if (on_leaf) {
+        double e;
+        if (slab_hit_entry_v(unit_f64(blob[1]), unit_f64(blob[2]), unit_f64(blob[3]), unit_f64(blob[4]), unit_f64(blob[5]), unit_f64(blob[6]), lr, tmin, tmax_hi, e)) {
+          leaf_entry = e; nq = 0;
+          const uint32_t end = (uint32_t)(blob[0] >> 32);
+          uint32_t p = i;
+          // the first two records from the registers where they are single static spheres, a pair of them, or
+          // general quads (units 7.. of the read are the leaf's)
+          const uint64_t u0 = blob[7];
+          const uint32_t k0 = RTX_NODE_KIND((uint32_t)u0), c0 = (uint32_t)(u0 >> 32);
+          if (p < end && QUADS && k0 == RTX_NODE_QUAD) {
+            note_quad(RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u); p += 1u;
+            const uint64_t u1 = blob[8];
+            const uint32_t k1 = RTX_NODE_KIND((uint32_t)u1);
+            if (p < end && k1 == RTX_NODE_QUAD) { note_quad(RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u; }
+            else if (p < end && k1 == PROG_NODE_SPHERE_S && (uint32_t)(u1 >> 32) == 1u) {
+              sphere_v(blob[9], blob[10], blob[11], blob[12], RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
+            }
+          } else if (p < end && k0 == PROG_NODE_SPHERE_S && c0 == 1u) {
+            sphere_v(blob[8], blob[9], blob[10], blob[11], RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
+            const uint64_t u1 = blob[12];
+            const uint32_t k1 = RTX_NODE_KIND((uint32_t)u1);
+            if (p < end && QUADS && k1 == RTX_NODE_QUAD) { note_quad(RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u; }
+            else if (p < end && k1 == PROG_NODE_SPHERE_S && (uint32_t)(u1 >> 32) == 1u) {
+              sphere_v(blob[13], blob[14], blob[15], blob16, RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
+            }
+          } else if (p < end && k0 == PROG_NODE_SPHERE_S && c0 == 2u) {
+            sphere_v(blob[8], blob[9], blob[10], blob[11], RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u);
+            sphere_v(blob[12], blob[13], blob[14], blob[15], RTX_NODE_IDX((uint32_t)u0) + 1u, (p << 6) + 2u);
+            p += 1u + 2u * PROG_SPHERE_S_UNITS;
+          }
+          rest_p = p; rest_end = end;       // whatever else the leaf holds: below, when the registers of the read are free
+          st = nq ? ST_QUAD : ST_POP;
+          RT_TRACE_STEP(32u + 1u);
+        } else st = ST_POP;
+      }
+    }
+    if (QUADS && RT_WAVE_ANY(on_quad)) {
+      if (on_quad) {   // rtx_quad: q, u, v, normal, w (three units each), d
+        double t;
+        const V3 qq = v3(unit_f64(blob[0]), unit_f64(blob[1]), unit_f64(blob[2])), qu = v3(unit_f64(blob[3]), unit_f64(blob[4]), unit_f64(blob[5]));
+        const V3 qv = v3(unit_f64(blob[6]), unit_f64(blob[7]), unit_f64(blob[8])), qn = v3(unit_f64(blob[9]), unit_f64(blob[10]), unit_f64(blob[11]));
+        const V3 qw = v3(unit_f64(blob[12]), unit_f64(blob[13]), unit_f64(blob[14]));
+        if (quad_hit_v(qn, unit_f64(blob[15]), qq, qw, qu, qv, lr.o, lr.d, tmin, tmax, t) && wins(t, qa_pos, true)) take_hit(t, RTX_NODE_MAKE(RTX_NODE_QUAD, qa_idx), qa_pos, true);
+        if (nq == 2u) { qa_idx = qb_idx; qa_pos = qb_pos; nq = 1u; } else { nq = 0u; st = ST_POP; }
+        RT_TRACE_STEP(32u + 4u);
+      }
+    }
+    if (RT_WAVE_ANY(rest_p < rest_end)) {   // records of a leaf that the read did not cover, or of another kind: from memory
+      if (rest_p < rest_end) records(rest_p, rest_end, false);
     }
   }
 }
