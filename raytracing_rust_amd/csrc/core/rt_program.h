@@ -51,6 +51,7 @@ struct CompiledProgram {
   uint32_t prog_units = 0;         // units of the program itself; tables for particular walks follow in `units`
   uint32_t head_top_begin = 0, head_top_nodes = 0, head_top_units = 0;   // Scene::head_top_*: the first levels of the head section's box tree
   uint32_t head_top_max_levels = 10;                 // 1023 records = 57 KB of LDS next to the walk's stacks
+  double head_wide_far = 0.0;
   uint32_t head_wide_begin = 0, head_wide_nodes = 0, head_wide_depth = 0; // Scene::head_wide_*: the head section's box tree, two levels per record
   bool head_wide = true;                             // build that table (tests switch it off to compare)
 
@@ -119,7 +120,7 @@ struct CompiledProgram {
     S.prog = units.data(); S.n_units = prog_units; S.tail_begin = tail_begin;
     S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr; S.near_margin = RT_NEAR_MARGIN;
     S.head_top_begin = head_top_begin; S.head_top_nodes = head_top_nodes; S.head_top_units = head_top_units;
-    S.head_wide_begin = head_wide_begin; S.head_wide_nodes = head_wide_nodes; S.head_wide_depth = head_wide_depth;
+    S.head_wide_begin = head_wide_begin; S.head_wide_nodes = head_wide_nodes; S.head_wide_depth = head_wide_depth; S._pad_wide = 0; S.head_wide_far = head_wide_far;
     return S;
   }
 
@@ -207,12 +208,16 @@ struct CompiledProgram {
   // word, high word 0), or the unit position behind the box of a leaf slot (low word; high word: where its units end,
   // never 0), or PROG_WIDE_EMPTY.  Records lie in depth-first order like the program (a subtree is one stretch of
   // memory); record 0 belongs to the section's root box.
-  // The table only CULLS: a ray that passes a box of the program passes the wider box here (every operation of
-  // Aabb::hit, aabb.rs:132-167, is monotone in the bounds), and it passes every box around it (a box contains its
-  // children's boxes exactly: aabb.rs:38-45 takes minima and maxima), so leaving the boxes in between untested loses
-  // nothing.  Whether a leaf's units are tested is decided by the program's own box record in front of them.
-  static float round_down(double v) { float f = (float)v; return (double)f > v ? nextafterf(f, -INFINITY) : f; }
-  static float round_up(double v) { float f = (float)v; return (double)f < v ? nextafterf(f, INFINITY) : f; }
+  // The table only CULLS: a ray that passes a box of the program passes the wider box here, and it passes every box
+  // around it (a box contains its children's boxes exactly: aabb.rs:38-45 takes minima and maxima; every operation of
+  // Aabb::hit, aabb.rs:132-167, is monotone in the bounds), so leaving the boxes in between untested loses nothing.
+  // Whether a leaf's units are tested is decided by the program's own box record in front of them.
+  // The bounds are padded by PROG_WIDE_PAD times the largest coordinate of the section's root box before they are
+  // rounded outward: the walk tests them with cheaper arithmetic than Aabb::hit's (one fused multiply-add per plane),
+  // whose rounding differs from the reference's by parts in 1e16 of (2|origin| + |bound|) / |direction|; for ray
+  // origins within head_wide_far = PROG_WIDE_FAR times that largest coordinate the pad is at least ten times that.
+  static float round_down(double v) { float f = (float)v; return (double)f >= v ? nextafterf(f, -INFINITY) : f; }
+  static float round_up(double v) { float f = (float)v; return (double)f <= v ? nextafterf(f, INFINITY) : f; }
   void build_head_wide() {
     head_wide_begin = 0; head_wide_nodes = 0; head_wide_depth = 0;
     uint32_t depth = 0;
@@ -220,6 +225,10 @@ struct CompiledProgram {
     auto is_box = [&](uint32_t p) { return p < head_end && RTX_NODE_KIND((uint32_t)units[p]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)units[p]) != PROG_GUARD_IDX; };
     auto inner = [&](uint32_t p) { return is_box(p) && is_box(p + PROG_BOX_UNITS) && is_box((uint32_t)(units[p + PROG_BOX_UNITS] >> 32)); };
     if (!inner(world_begin)) return;
+    double extent = 0.0;
+    for (uint32_t j = 0; j < 6; ++j) { double v; memcpy(&v, &units[world_begin + 1 + j], 8); extent = std::max(extent, fabs(v)); }
+    if (!(extent > 0.0) || !(extent < 1e300)) return;
+    const double pad = extent * PROG_WIDE_PAD;
     std::vector<uint64_t> table;
     bool ok = true;
     // emits the record of inner box p (and, behind it, the records of its inner slots); returns its index
@@ -241,7 +250,7 @@ struct CompiledProgram {
           float f[6];
           for (uint32_t j = 0; j < 6; ++j) {
             double v; memcpy(&v, &units[q + 1 + j], 8);
-            f[j] = j < 3 ? round_down(v) : round_up(v);
+            f[j] = j < 3 ? round_down(v - pad) : round_up(v + pad);
           }
           memcpy((char*)(table.data() + (size_t)me * PROG_WIDE_UNITS) + 24u * k, f, 24);
           if (inner(q)) desc = (uint64_t)emit(q, level + 1);
@@ -255,6 +264,7 @@ struct CompiledProgram {
     while (units.size() & 15u) units.push_back(nop());
     if (!ok || units.size() + table.size() + 64u >= (1ull << 31)) return;   // unit positions of leaves go on the stack with a flag bit
     head_wide_begin = (uint32_t)units.size(); head_wide_nodes = (uint32_t)(table.size() / PROG_WIDE_UNITS); head_wide_depth = depth;
+    head_wide_far = extent * PROG_WIDE_FAR;
     units.insert(units.end(), table.begin(), table.end());
   }
   static uint64_t nop() { return (uint64_t)RTX_NODE_MAKE(PROG_NODE_NOP, 0); }

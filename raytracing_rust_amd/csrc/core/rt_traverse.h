@@ -78,8 +78,11 @@ struct Scene : rtx_scene_desc {
   // The head section's box tree with two levels folded into one (CompiledProgram::build_head_wide), for the walk of a
   // section that stays in global memory: head_wide_nodes records of PROG_WIDE_UNITS units from unit head_wide_begin
   // (a multiple of 16: records are 128-byte aligned), the root's children first.  0 nodes = none.
-  uint32_t head_wide_begin, head_wide_nodes, head_wide_depth;   // depth: records on the longest way down
+  uint32_t head_wide_begin, head_wide_nodes, head_wide_depth, _pad_wide;   // depth: records on the longest way down
+  double head_wide_far;   // the table serves rays whose origin coordinates are within this (see build_head_wide)
 };
+#define PROG_WIDE_PAD 1e-9                 // pad of the table's bounds, relative to the section's largest coordinate
+#define PROG_WIDE_FAR 1e5                  // origins this many times farther out than that are walked over the program
 #define PROG_WIDE_UNITS 16u                // four boxes (6 floats each, rounded outward), four slot descriptors
 #define PROG_WIDE_EMPTY 0xFFFFFFFFFFFFFFFFull   // slot descriptor: no box in this slot
 // record sizes in units (header included)
@@ -1143,6 +1146,24 @@ RT_HD bool slab_hit_entry_v(double lx, double ly, double lz, double hx, double h
   entry = tmin;
   return !(tmax <= tmin);
 }
+// A padded box of the folded table against a ray: the slab test with one fused multiply-add per plane (oi = o * inv).
+// Only for culling: see CompiledProgram::build_head_wide for why it never fails a box that Aabb::hit passes.
+RT_HD bool slab_cull_entry(double lx, double ly, double lz, double hx, double hy, double hz, const LRay& r, const V3& oi, double tmin, double tmax, double& entry) {
+  const double ax = fma(lx, r.inv.x, -oi.x), bx = fma(hx, r.inv.x, -oi.x);
+  const double ay = fma(ly, r.inv.y, -oi.y), by = fma(hy, r.inv.y, -oi.y);
+  const double az = fma(lz, r.inv.z, -oi.z), bz = fma(hz, r.inv.z, -oi.z);
+  double nrx = rt_min(ax, bx), frx = rt_max(ax, bx), nry = rt_min(ay, by), fry = rt_max(ay, by), nrz = rt_min(az, bz), frz = rt_max(az, bz);
+  if (r.skip & 7u) {
+    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
+    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
+    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
+  }
+  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
+  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
+  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
+  entry = tmin;
+  return !(tmax <= tmin);
+}
 RT_HD double unit_f64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 RT_HD double unit_f32(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return (double)f; }
 struct alignas(16) UnitPair { uint64_t x, y; };
@@ -1309,10 +1330,14 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         id = nid; rs = feed.ray(id);
         feed.start(id, tmax, hit_kind, hit_ctx); tmax_hi = tmax + tmax * S.near_margin;
         lr = lray_from_ops(prog, 0, rs.origin(), rs.dir());
-        have = true; sp = 0; nq = 0; suspect = (lr.skip & 8u) != 0u; leaf_entry = -RT_INF;
+        have = true; sp = 0; nq = 0; leaf_entry = -RT_INF;
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
-        // the root box, alone; its children are the table's first record
-        node = 0; st = (!suspect && slab_hit((const double*)(prog + begin + 1), lr, tmin, tmax_hi)) ? ST_NODE : ST_POP;
+        // the root box, alone, as the reference tests it; its children are the table's first record.  A ray that is
+        // not finite, or starts too far out for the table's pad to cover the rounding of its tests, goes the program's way.
+        const bool root = slab_hit((const double*)(prog + begin + 1), lr, tmin, tmax_hi);
+        const bool far = (lr.skip & 8u) != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
+        suspect = root && far;
+        node = 0; st = (root && !far) ? ST_NODE : ST_POP;
       }
     }
     if (!RT_WAVE_ANY(have)) {
@@ -1338,13 +1363,15 @@ RT_UNROLL
     if (RT_WAVE_ANY(on_node)) {
       if (on_node) {
         double e0 = RT_INF, e1 = RT_INF, e2 = RT_INF, e3 = RT_INF;
+        const V3 oi = v3(lr.o.x * lr.inv.x, lr.o.y * lr.inv.y, lr.o.z * lr.inv.z);   // (three multiplications a step cost less than six registers)
         const uint64_t d0 = blob[12], d1 = blob[13], d2 = blob[14], d3 = blob[15];
-        if (!(d0 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[0], 0), unit_f32(blob[0], 1), unit_f32(blob[1], 0), unit_f32(blob[1], 1), unit_f32(blob[2], 0), unit_f32(blob[2], 1), lr, tmin, tmax_hi, e0))) e0 = RT_INF;
-        if (!(d1 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[3], 0), unit_f32(blob[3], 1), unit_f32(blob[4], 0), unit_f32(blob[4], 1), unit_f32(blob[5], 0), unit_f32(blob[5], 1), lr, tmin, tmax_hi, e1))) e1 = RT_INF;
-        if (!(d2 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[6], 0), unit_f32(blob[6], 1), unit_f32(blob[7], 0), unit_f32(blob[7], 1), unit_f32(blob[8], 0), unit_f32(blob[8], 1), lr, tmin, tmax_hi, e2))) e2 = RT_INF;
-        if (!(d3 != PROG_WIDE_EMPTY && slab_hit_entry_v(unit_f32(blob[9], 0), unit_f32(blob[9], 1), unit_f32(blob[10], 0), unit_f32(blob[10], 1), unit_f32(blob[11], 0), unit_f32(blob[11], 1), lr, tmin, tmax_hi, e3))) e3 = RT_INF;
+        if (!(d0 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[0], 0), unit_f32(blob[0], 1), unit_f32(blob[1], 0), unit_f32(blob[1], 1), unit_f32(blob[2], 0), unit_f32(blob[2], 1), lr, oi, tmin, tmax_hi, e0))) e0 = RT_INF;
+        if (!(d1 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[3], 0), unit_f32(blob[3], 1), unit_f32(blob[4], 0), unit_f32(blob[4], 1), unit_f32(blob[5], 0), unit_f32(blob[5], 1), lr, oi, tmin, tmax_hi, e1))) e1 = RT_INF;
+        if (!(d2 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[6], 0), unit_f32(blob[6], 1), unit_f32(blob[7], 0), unit_f32(blob[7], 1), unit_f32(blob[8], 0), unit_f32(blob[8], 1), lr, oi, tmin, tmax_hi, e2))) e2 = RT_INF;
+        if (!(d3 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[9], 0), unit_f32(blob[9], 1), unit_f32(blob[10], 0), unit_f32(blob[10], 1), unit_f32(blob[11], 0), unit_f32(blob[11], 1), lr, oi, tmin, tmax_hi, e3))) e3 = RT_INF;
         // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
-        // (an entry is finite: the lower bound it starts from is)
+        // (an entry is finite: the lower bound it starts from is).  Only the nearest in front and the others in the
+        // program's order measured the same: 165 against 167 Msamples/s on the stress scene.
         uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
 #define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const double te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
         RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)

@@ -1526,7 +1526,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.world_begin = prog.world_begin; sc->dev.world_end = 0;
   sc->dev.n_units = prog.prog_units; sc->dev.tail_begin = prog.tail_begin;
   sc->dev.head_end = prog.head_end; sc->dev.tail_near_depth = prog.tail_near_depth; sc->dev.head_near_depth = prog.head_near_depth; sc->dev.tail_near_quads = prog.tail_near_quads; sc->dev._pad_near = 0; sc->dev.fresh_in_main = 0; sc->dev.light_quads = nullptr; sc->dev.light_spheres = nullptr; sc->dev.near_margin = RT_NEAR_MARGIN; sc->dev.head_top_begin = prog.head_top_begin; sc->dev.head_top_nodes = prog.head_top_nodes; sc->dev.head_top_units = prog.head_top_units;
-  sc->dev.head_wide_begin = prog.head_wide_begin; sc->dev.head_wide_nodes = prog.head_wide_nodes; sc->dev.head_wide_depth = prog.head_wide_depth;
+  sc->dev.head_wide_begin = prog.head_wide_begin; sc->dev.head_wide_nodes = prog.head_wide_nodes; sc->dev.head_wide_depth = prog.head_wide_depth; sc->dev._pad_wide = 0; sc->dev.head_wide_far = prog.head_wide_far;
   sc->n_general_media = prog.n_general_media;
   sc->nothing_behind_head = false;
   if (prog.head_end && !prog.tail_begin && d->n_media == 0) {
