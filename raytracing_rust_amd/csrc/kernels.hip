@@ -758,6 +758,84 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
   if (blockIdx.x == 0 && threadIdx.x == 0) c->finished = 1u;  // the next k_wf_prepare drops the survivors
 }
 
+// The same tail of a call for a program whose world program and deferred section each fit LDS: a workgroup keeps its
+// 512 survivors to their end and walks every bounce from LDS, the world program staged first (a ray that passes the
+// deferred section's root box is noted, as in the wavefront traversal) and the deferred section's program after it for
+// the rays noted - the walk of world.hit cut in two, bit for bit.  From global memory a step of the walk costs a round
+// trip to the L2 (k_wf_finish: 220 us per bounce on the final scene); from LDS a third of that.
+#define RT_FINISH_THREADS 512
+template <int MM>
+__global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
+                                                                    int use_lights, uint32_t threshold, WfCounters* c, WfQueue qin,
+                                                                    double* __restrict__ accum, unsigned long long* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t lds_prog[];
+  const uint32_t n = c->n_out;  // survivors of the last shading launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) wf_flush_timing(c);
+  if (n == 0 || n > threshold || c->next_path != c->total_paths) return;
+  if (blockIdx.x * blockDim.x >= n) return;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const V3 bg = v3(cam.background);
+  bool alive = idx < n;
+  const uint32_t ld = alive ? idx : 0;
+  const double* f = qin.f + ld;
+  Ray ray;
+  ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
+  ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
+  ray.tm = f[6 * (size_t)cap];
+  PathState ps;
+  ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
+  ps.L = v3(0.0, 0.0, 0.0);
+  const uint32_t* u = qin.u + ld;
+  const uint32_t pixel = u[0], sample = u[(size_t)cap], db = u[2 * (size_t)cap];
+  ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
+  ps.rng = rng_make(seed, pixel, sample);
+  alive = alive && ps.depth > 0;   // a dead entry of the shading kernel
+  uint32_t segs = 0, probes = 0;
+  const uint32_t main_units = S.tail_begin ? S.tail_begin : S.n_units, tail_units = S.tail_begin ? S.n_units - S.tail_begin : 0u;   // both even
+  while (__syncthreads_or(alive ? 1 : 0)) {   // (the barrier also keeps the staged image until every wave is through with it)
+    {
+      const uint4* src = (const uint4*)S.prog;
+      uint4* dst = (uint4*)lds_prog;
+      for (uint32_t k = threadIdx.x; k < main_units / 2; k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+    Hit hit;
+    double stale_uv[2] = {0.0, 0.0};
+    if (alive) ++segs;
+    RayRegs rs;
+    rs.r = ray;
+    const bool deferred = walk_program<MM, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, ps.rng, ps.bounce, stale_uv);
+    if (tail_units) {
+      __syncthreads();
+      const uint4* src = (const uint4*)(S.prog + S.tail_begin);
+      uint4* dst = (uint4*)lds_prog;
+      for (uint32_t k = threadIdx.x; k < tail_units / 2; k += blockDim.x) dst[k] = src[k];
+      __syncthreads();
+      const bool in_section = alive && deferred;
+      Hit h2;
+      walk_program<MEDIA_NONE, false>(S, lds_prog - S.tail_begin, S.tail_begin, in_section, rs, ray.tm, 0.001, hit.t, h2, false, ps.rng, ps.bounce, stale_uv);
+      if (in_section && hit_any(h2)) hit = h2;
+    }
+    if (alive) {
+      Ray next;
+      ps.L = v3(0.0, 0.0, 0.0);
+      alive = shade_bounce(S, bg, use_lights != 0, ray, hit, stale_uv, ps, next, probes);
+      ray = next;
+      if (!alive && (ps.L.x != 0.0 || ps.L.y != 0.0 || ps.L.z != 0.0)) {
+        double* a = accum + (size_t)pixel * 3;
+        unsafeAtomicAdd(a + 0, ps.L.x); unsafeAtomicAdd(a + 1, ps.L.y); unsafeAtomicAdd(a + 2, ps.L.z);
+      }
+    }
+  }
+  __shared__ unsigned int sh[2];
+  if (threadIdx.x < 2) sh[threadIdx.x] = 0;
+  __syncthreads();
+  atomicAdd(&sh[0], segs); atomicAdd(&sh[1], probes);
+  __syncthreads();
+  if (threadIdx.x < 2 && sh[threadIdx.x]) atomicAdd(&stats[1 + threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->finished = 1u;  // the next k_wf_prepare drops the survivors
+}
+
 // ------------------------------------------------------------ fused path ---
 // Fused path tracer: one lane owns one pixel and walks its samples one after another.  Every trip of the loop is
 // one segment for every lane of the wave (closest hit, then shading), so the wave stays in one phase; a lane whose
@@ -1062,6 +1140,7 @@ static const size_t kLdsBudget = 160 * 1024;  // gfx950: 160 KiB of LDS per CU, 
 // Every traversal kernel instantiation that is launched with dynamic LDS (the staged program, the waves' defer
 // buffers, the lanes' stacks of the nearer-child-first walk: up to the whole 160 KiB) is given that limit once, when
 // the first context is created.
+static const size_t kFinishLdsBudget = kLdsBudget - 1024;
 static hipError_t wf_set_lds_limits() {
   const void* kernels[] = {
       (const void*)k_wf_traverse<true, false, MEDIA_NONE>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, (const void*)k_wf_traverse<true, false, MEDIA_ALL>,
@@ -1073,6 +1152,11 @@ static hipError_t wf_set_lds_limits() {
       (const void*)k_wf_stream<true, true, 2>, (const void*)k_wf_stream<false, true, 2>};
   for (const void* k : kernels) {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e != hipSuccess) return e;
+  }
+  const void* finishers[] = {(const void*)k_wf_finish_lds<MEDIA_NONE>, (const void*)k_wf_finish_lds<MEDIA_SPHERES>, (const void*)k_wf_finish_lds<MEDIA_ALL>};
+  for (const void* k : finishers) {   // (this kernel also has a few bytes of static LDS)
+    const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFinishLdsBudget);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -1138,6 +1222,9 @@ struct WfPlan {
   bool skip_main = false;
   void (*k_main)(Scene, uint32_t, unsigned long long, WfCounters*, WfQueue, WfHits, uint32_t*, unsigned long long*, rtx_camera_desc, WfFrame) = nullptr;
   unsigned trav_blocks = 0, gen_blocks = 0, shade_blocks = 0;
+  // the finishing kernel that walks from LDS, when the world program and the deferred section each fit (else null)
+  void (*k_finish_lds)(Scene, rtx_camera_desc, uint32_t, unsigned long long, int, uint32_t, WfCounters*, WfQueue, double*, unsigned long long*) = nullptr;
+  size_t finish_lds_bytes = 0;
 };
 
 static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long share) {   // share: camera paths per pipeline of the call
@@ -1229,6 +1316,14 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
   P.k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
            : P.main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
                         : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
+  {
+    const size_t whole_main = (size_t)(tail_begin ? tail_begin : n_units) * 8;
+    const char* fe = getenv("RTX_WF_FINISH_LDS");   // 0: the finishing kernel walks the program in global memory
+    if (whole_main <= kFinishLdsBudget && P.tail_bytes <= kFinishLdsBudget && !(fe && atoi(fe) == 0)) {
+      P.k_finish_lds = mm == MEDIA_NONE ? k_wf_finish_lds<MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_finish_lds<MEDIA_SPHERES> : k_wf_finish_lds<MEDIA_ALL>;
+      P.finish_lds_bytes = std::max(whole_main, P.tail_bytes);
+    }
+  }
   const unsigned blocks256 = cap / 256;
   P.trav_blocks = (unsigned)ctx->n_cus;
   P.gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
@@ -1356,7 +1451,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   // first was nearly through: the host needs about a millisecond to enqueue a chunk).  HIP event pairs around the
   // section launches only with a single pipeline: side by side the spans would overlap, and four event records per
   // iteration are a fifth of the host's work here.
-  int chunk = 8;
+  int chunk = 4;   // (8: quick 1081, 4: 1097-1114 Msamples/s; the large render does not care)
   if (const char* e = getenv("RTX_WF_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 64) chunk = v & ~1; }   // even: the queues swap roles every iteration
   const bool timed_sections = n_lanes == 1;
   for (bool all_done = false; !all_done;) {
@@ -1373,7 +1468,10 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       if (r.done || r.closed) continue;
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
-      hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+      if (P.k_finish_lds)
+        hipLaunchKernelGGL(P.k_finish_lds, dim3((finish_threshold() + RT_FINISH_THREADS - 1) / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+      else
+        hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(&L.host[r.k & 1], L.c, sizeof(WfCounters), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipEventRecord(L.ev[r.k & 1], s));

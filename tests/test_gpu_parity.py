@@ -413,6 +413,36 @@ def test_parallel_pipelines_trace_the_same_paths(gpu_ctx, monkeypatch):
     scene.close()
 
 
+@pytest.mark.parametrize("name,kw", [("final", dict(width=160, spp=16, depth=40)), ("smoke", dict(width=128, spp=16, depth=30)),
+                                     ("cornell", dict(width=128, spp=16, depth=30))])
+def test_finishing_kernels_trace_the_same_paths(gpu_ctx, monkeypatch, name, kw):
+    """Once a pipeline has no new camera paths left and few survivors, one launch runs them to their end: walking the
+    program from LDS, the world program and the deferred section staged in turn (the default where both fit), or from
+    global memory (RTX_WF_FINISH_LDS=0); it takes over at RTX_WF_FINISH survivors.  Early, late or never, with either
+    kernel, the paths are the fused pipeline's (final: media of both kinds of boundary next to the deferred cluster;
+    smoke: box-bounded media; cornell: no media)."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build(name, gp, **kw)
+    scene = rt.Scene.from_graph(gpu_ctx, gp, wp, lp)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=77, pipeline=_capi.PIPELINE_FUSED))
+    sa = gpu_ctx.stats()
+    monkeypatch.setenv("RTX_WF_LANES", "2")
+    for lds, finish in (("1", "4194304"), ("1", "8192"), ("0", "4194304"), ("1", "256")):
+        monkeypatch.setenv("RTX_WF_FINISH_LDS", lds)
+        monkeypatch.setenv("RTX_WF_FINISH", finish)
+        gpu_ctx.reset_stats()
+        b = scene.render(cam, rt.render_opts(cam, seed=77, pipeline=_capi.PIPELINE_WAVEFRONT))
+        sb = gpu_ctx.stats()
+        assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"], (lds, finish)
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+        # a threshold above the whole call hands every path to the finishing kernel after the first iterations
+        if finish == "4194304":
+            assert sb["iterations"] <= 2 * 8
+    assert a.sum() > 0
+    scene.close()
+
+
 def test_calls_on_different_streams_do_not_overlap_in_the_workspace(gpu_ctx):
     """Two render calls of one context, back to back on two different streams: they share the context's wavefront
     workspace and counters, so the library orders the second behind the first (an event on the first call's stream).
