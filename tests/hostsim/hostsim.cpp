@@ -10,6 +10,7 @@ static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 #define RT_TRACE_STEP(kind) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = (uint8_t)(kind); } while (0)
 #include <atomic>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include "../../raytracing_rust_amd/csrc/core/rt_program.h"
@@ -146,6 +147,69 @@ int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t 
   }
   g_near_walks = near_walks; g_redos = redos;
   return streamed;
+}
+
+// Invariants of the folded table of a head section in global memory (CompiledProgram::build_head_wide), checked
+// against the program it was made from.  Returns the number of leaf slots, 0 if the program has no such table, and a
+// negative number naming the first violated invariant.
+long sim_check_wide_table(const rtx_scene_desc* desc, uint32_t* n_records, uint32_t* depth) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  if (!prog.head_wide_nodes) return 0;
+  const std::vector<uint64_t>& u = prog.units;
+  if (prog.head_wide_begin % 16u) return -1;                                       // records are 128-byte aligned
+  if ((size_t)prog.head_wide_begin + (size_t)prog.head_wide_nodes * PROG_WIDE_UNITS != u.size()) return -2;
+  auto is_box = [&](uint32_t p) { return p < prog.head_end && RTX_NODE_KIND((uint32_t)u[p]) == RTX_NODE_BOX && RTX_NODE_IDX((uint32_t)u[p]) != PROG_GUARD_IDX; };
+  // leaf boxes of the program's tree, in program order
+  std::vector<uint32_t> leaves;
+  for (uint32_t p = prog.world_begin; p < prog.head_end; p += prog_record_units(u[p]))
+    if (is_box(p) && !is_box(p + PROG_BOX_UNITS)) leaves.push_back(p + PROG_BOX_UNITS);
+  std::vector<uint32_t> seen;
+  std::vector<char> visited(prog.head_wide_nodes, 0);
+  uint32_t max_depth = 0;
+  long bad = 0;
+  // every record: its slots' boxes contain the program's boxes they stand for, with room; a slot's record lies behind it
+  std::function<void(uint32_t, uint32_t, uint32_t)> walk = [&](uint32_t rec, uint32_t box_pos, uint32_t level) {
+    if (bad) return;
+    if (rec >= prog.head_wide_nodes || visited[rec]) { bad = -3; return; }
+    visited[rec] = 1;
+    max_depth = std::max(max_depth, level + 1u);
+    // the program boxes this record's slots stand for: grandchildren of box_pos, or a child that is a leaf
+    uint32_t slots[4], n = 0;
+    const uint32_t c0 = box_pos + PROG_BOX_UNITS, c1 = (uint32_t)(u[c0] >> 32);
+    for (uint32_t c : {c0, c1}) {
+      if (is_box(c + PROG_BOX_UNITS)) { slots[n++] = c + PROG_BOX_UNITS; slots[n++] = (uint32_t)(u[c + PROG_BOX_UNITS] >> 32); }
+      else slots[n++] = c;
+    }
+    const uint64_t* r = u.data() + prog.head_wide_begin + (size_t)rec * PROG_WIDE_UNITS;
+    const float* fb = (const float*)r;
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint64_t d = r[12 + k];
+      if (k >= n) { if (d != PROG_WIDE_EMPTY) bad = -4; continue; }
+      const uint32_t q = slots[k];
+      for (uint32_t j = 0; j < 6; ++j) {
+        double v; memcpy(&v, &u[q + 1 + j], 8);
+        const double f = (double)fb[6 * k + j];
+        if (j < 3 ? !(f < v) : !(f > v)) { bad = -5; return; }                     // strictly outside the program's box
+      }
+      if (is_box(q + PROG_BOX_UNITS)) {
+        if ((d >> 32) != 0ull || (uint32_t)d <= rec) { bad = -6; return; }         // depth first: a child record lies behind
+        walk((uint32_t)d, q, level + 1u);
+      } else {
+        if ((uint32_t)d != q + PROG_BOX_UNITS || (uint32_t)(d >> 32) != (uint32_t)(u[q] >> 32) || (d >> 32) == 0ull) { bad = -7; return; }
+        seen.push_back((uint32_t)d);
+      }
+    }
+  };
+  walk(0u, prog.world_begin, 0u);
+  if (bad) return bad;
+  for (char v : visited) if (!v) return -8;                                        // no record is unreachable
+  if (seen != leaves) return -9;                                                   // every leaf once, in program order
+  if (max_depth != prog.head_wide_depth) return -10;
+  if (!(prog.head_wide_far > 0.0)) return -11;
+  if (n_records) *n_records = prog.head_wide_nodes;
+  if (depth) *depth = prog.head_wide_depth;
+  return (long)seen.size();
 }
 
 void sim_set_near(int mode) { g_near = mode; }

@@ -148,6 +148,29 @@ def test_folded_table_walk_hands_rays_back_to_the_program_order():
     assert seen[0] <= 2 and seen[1] > 50 and seen[2] > seen[1], seen
 
 
+@pytest.mark.parametrize("n_prims", [30000, 30001, 50021])
+def test_folded_table_covers_the_program(n_prims):
+    """The table that folds two levels of a large head section's box tree into one record, against the program it was
+    made from: every record reachable once, depth first; every slot's float box strictly around the program box it
+    stands for; the boxes left out are exactly those whose two children are boxes; every leaf of the tree appears
+    once, in the program's order, with the position and end of its units; the stated depth is the deepest record's."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("stress", gp, width=64, n_prims=n_prims)
+    d = rt.flatten(gp, wp, lp)
+    lib = H.hostsim_lib()
+    lib.sim_check_wide_table.restype = ctypes.c_long
+    nrec, depth = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    leaves = lib.sim_check_wide_table(ctypes.byref(d), ctypes.byref(nrec), ctypes.byref(depth))
+    assert leaves > 0, leaves
+    # a BvhNode over n objects has one lowest box per pair of objects (bvh.rs:36-57); boxes with two box children get a record
+    assert leaves == 2 ** 14 if n_prims <= 2 ** 15 else leaves == 2 ** 15
+    assert 3 <= depth.value <= 10 and leaves // 4 < nrec.value < leaves
+    # the shipped scenes are walked from LDS and get no such table
+    gq = rt.Graph()
+    wq, lq, _ = scenes.build("final", gq, width=32)
+    assert lib.sim_check_wide_table(ctypes.byref(rt.flatten(gq, wq, lq)), None, None) == 0
+
+
 def test_nearer_child_first_hands_back_what_depends_on_the_order():
     """The one case in which the visiting order can change a closest hit: a hit on the boundary of its own bounding box
     that ties with another (recipes.ties_on_box_boundaries is made of them).  The nearer-child-first walk notices such
