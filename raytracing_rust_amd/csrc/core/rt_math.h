@@ -27,11 +27,7 @@
 namespace rt {
 
 #define RT_PI 3.14159265358979323846
-#if defined(__HIPCC__)
 #define RT_INF (__builtin_huge_val())
-#else
-#define RT_INF (__builtin_huge_val())
-#endif
 
 // sin and cos of one angle (vec3.rs:66-68, sphere.rs:74-76 call them one after the other): one argument reduction
 // on the GPU instead of two.
