@@ -213,9 +213,10 @@ struct CompiledProgram {
   // Aabb::hit, aabb.rs:132-167, is monotone in the bounds), so leaving the boxes in between untested loses nothing.
   // Whether a leaf's units are tested is decided by the program's own box record in front of them.
   // The bounds are padded by PROG_WIDE_PAD times the largest coordinate of the section's root box before they are
-  // rounded outward: the walk tests them with cheaper arithmetic than Aabb::hit's (one fused multiply-add per plane),
-  // whose rounding differs from the reference's by parts in 1e16 of (2|origin| + |bound|) / |direction|; for ray
-  // origins within head_wide_far = PROG_WIDE_FAR times that largest coordinate the pad is at least ten times that.
+  // rounded outward: the walk tests them in single precision with one fused multiply-add per plane, measuring ray
+  // parameters from where the ray enters the root box (slab_cull_entry_f), and its results differ from Aabb::hit's by
+  // at most 2.4e-7 of that largest coordinate in space units, an eighth of the pad, for ray origins within
+  // head_wide_far = PROG_WIDE_FAR times it (beyond that the shift of the origin itself loses digits).
   static float round_down(double v) { float f = (float)v; return (double)f >= v ? nextafterf(f, -INFINITY) : f; }
   static float round_up(double v) { float f = (float)v; return (double)f <= v ? nextafterf(f, INFINITY) : f; }
   void build_head_wide() {

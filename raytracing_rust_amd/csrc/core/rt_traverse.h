@@ -81,8 +81,8 @@ struct Scene : rtx_scene_desc {
   uint32_t head_wide_begin, head_wide_nodes, head_wide_depth, _pad_wide;   // depth: records on the longest way down
   double head_wide_far;   // the table serves rays whose origin coordinates are within this (see build_head_wide)
 };
-#define PROG_WIDE_PAD 1e-9                 // pad of the table's bounds, relative to the section's largest coordinate
-#define PROG_WIDE_FAR 1e5                  // origins this many times farther out than that are walked over the program
+#define PROG_WIDE_PAD 2e-6                 // pad of the table's bounds, relative to the section's largest coordinate
+#define PROG_WIDE_FAR 1e9                  // origins this many times farther out than that are walked over the program
 #define PROG_WIDE_UNITS 16u                // four boxes (6 floats each, rounded outward), four slot descriptors
 #define PROG_WIDE_EMPTY 0xFFFFFFFFFFFFFFFFull   // slot descriptor: no box in this slot
 // record sizes in units (header included)
@@ -1164,6 +1164,29 @@ RT_HD bool slab_cull_entry(double lx, double ly, double lz, double hx, double hy
   entry = tmin;
   return !(tmax <= tmin);
 }
+// The same in single precision, on the table's floats as they are: near and far plane distances by one fused
+// multiply-add each from inv and oi = o * inv rounded to float.  Their error is at most (|bound| + |origin|) |inv| 1.2e-7.
+// The caller measures ray parameters from where the ray enters the section's root box (oi = o * inv + shift is the
+// same ray with its origin moved there: d * inv = 1 on every axis that counts), so |origin| is within the section's
+// extent whatever the ray's own origin, and the table's pad (PROG_WIDE_PAD of the extent) exceeds the error eight
+// times over; tmin and tmax, measured from the same point, must be rounded outward by the caller.
+RT_HD bool slab_cull_entry_f(float lx, float ly, float lz, float hx, float hy, float hz, float ix, float iy, float iz, float ox, float oy, float oz,
+                             uint32_t skip, float tmin, float tmax, float& entry) {
+  const float ax = fmaf(lx, ix, -ox), bx = fmaf(hx, ix, -ox);
+  const float ay = fmaf(ly, iy, -oy), by = fmaf(hy, iy, -oy);
+  const float az = fmaf(lz, iz, -oz), bz = fmaf(hz, iz, -oz);
+  float nrx = fminf(ax, bx), frx = fmaxf(ax, bx), nry = fminf(ay, by), fry = fmaxf(ay, by), nrz = fminf(az, bz), frz = fmaxf(az, bz);
+  if (skip & 7u) {
+    if (skip & 1u) { nrx = -(float)RT_INF; frx = (float)RT_INF; }
+    if (skip & 2u) { nry = -(float)RT_INF; fry = (float)RT_INF; }
+    if (skip & 4u) { nrz = -(float)RT_INF; frz = (float)RT_INF; }
+  }
+  tmin = fmaxf(tmin, fmaxf(nrx, fmaxf(nry, nrz)));
+  tmax = fminf(tmax, fminf(frx, fminf(fry, frz)));
+  entry = tmin;
+  return !(tmax <= tmin);
+}
+RT_HD float unit_f32f(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return f; }
 RT_HD double unit_f64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 RT_HD double unit_f32(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return (double)f; }
 struct alignas(16) UnitPair { uint64_t x, y; };
@@ -1276,6 +1299,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
   double leaf_entry = -RT_INF, tmax_hi = RT_INF, tmax = RT_INF;
   uint32_t id = 0, st = ST_POP, node = 0, i = begin, sp = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
   uint32_t nq = 0, qa_idx = 0, qa_pos = 0, qb_idx = 0, qb_pos = 0;   // quads of the current leaf still to test
+  float shift = 0.0f;   // the table's tests measure ray parameters from here: where the ray enters the root box
   auto rs = feed.ray(0);
   LRay lr;
   lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
@@ -1334,7 +1358,9 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         best_pos = 0; best_quad = RTX_NODE_KIND(hit_kind) == RTX_NODE_QUAD;
         // the root box, alone, as the reference tests it; its children are the table's first record.  A ray that is
         // not finite, or starts too far out for the table's pad to cover the rounding of its tests, goes the program's way.
-        const bool root = slab_hit((const double*)(prog + begin + 1), lr, tmin, tmax_hi);
+        double root_entry = 0.0;
+        const bool root = slab_hit_entry((const double*)(prog + begin + 1), lr, tmin, tmax_hi, root_entry);
+        shift = (float)root_entry;
         const bool far = (lr.skip & 8u) != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
         suspect = root && far;
         node = 0; st = (root && !far) ? ST_NODE : ST_POP;
@@ -1362,18 +1388,24 @@ RT_UNROLL
     }
     if (RT_WAVE_ANY(on_node)) {
       if (on_node) {
-        double e0 = RT_INF, e1 = RT_INF, e2 = RT_INF, e3 = RT_INF;
-        const V3 oi = v3(lr.o.x * lr.inv.x, lr.o.y * lr.inv.y, lr.o.z * lr.inv.z);   // (three multiplications a step cost less than six registers)
+        const float FINF = (float)RT_INF;
+        float e0 = FINF, e1 = FINF, e2 = FINF, e3 = FINF;
+        // the ray in single precision (made here every step: a few instructions cost less than six registers), the
+        // interval rounded outward
+        const float ix = (float)lr.inv.x, iy = (float)lr.inv.y, iz = (float)lr.inv.z;
+        const double sh = (double)shift, lo_t = tmin - sh, hi_t = tmax_hi - sh;
+        const float ox = (float)(lr.o.x * lr.inv.x + sh), oy = (float)(lr.o.y * lr.inv.y + sh), oz = (float)(lr.o.z * lr.inv.z + sh);
+        const float tlo = (float)(lo_t - fabs(lo_t) * 2e-7 - 1e-30), thi = (float)(hi_t + fabs(hi_t) * 2e-7 + 1e-30);
         const uint64_t d0 = blob[12], d1 = blob[13], d2 = blob[14], d3 = blob[15];
-        if (!(d0 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[0], 0), unit_f32(blob[0], 1), unit_f32(blob[1], 0), unit_f32(blob[1], 1), unit_f32(blob[2], 0), unit_f32(blob[2], 1), lr, oi, tmin, tmax_hi, e0))) e0 = RT_INF;
-        if (!(d1 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[3], 0), unit_f32(blob[3], 1), unit_f32(blob[4], 0), unit_f32(blob[4], 1), unit_f32(blob[5], 0), unit_f32(blob[5], 1), lr, oi, tmin, tmax_hi, e1))) e1 = RT_INF;
-        if (!(d2 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[6], 0), unit_f32(blob[6], 1), unit_f32(blob[7], 0), unit_f32(blob[7], 1), unit_f32(blob[8], 0), unit_f32(blob[8], 1), lr, oi, tmin, tmax_hi, e2))) e2 = RT_INF;
-        if (!(d3 != PROG_WIDE_EMPTY && slab_cull_entry(unit_f32(blob[9], 0), unit_f32(blob[9], 1), unit_f32(blob[10], 0), unit_f32(blob[10], 1), unit_f32(blob[11], 0), unit_f32(blob[11], 1), lr, oi, tmin, tmax_hi, e3))) e3 = RT_INF;
+        if (!(d0 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[0], 0), unit_f32f(blob[0], 1), unit_f32f(blob[1], 0), unit_f32f(blob[1], 1), unit_f32f(blob[2], 0), unit_f32f(blob[2], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e0))) e0 = FINF;
+        if (!(d1 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[3], 0), unit_f32f(blob[3], 1), unit_f32f(blob[4], 0), unit_f32f(blob[4], 1), unit_f32f(blob[5], 0), unit_f32f(blob[5], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e1))) e1 = FINF;
+        if (!(d2 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[6], 0), unit_f32f(blob[6], 1), unit_f32f(blob[7], 0), unit_f32f(blob[7], 1), unit_f32f(blob[8], 0), unit_f32f(blob[8], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e2))) e2 = FINF;
+        if (!(d3 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[9], 0), unit_f32f(blob[9], 1), unit_f32f(blob[10], 0), unit_f32f(blob[10], 1), unit_f32f(blob[11], 0), unit_f32f(blob[11], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e3))) e3 = FINF;
         // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
         // (an entry is finite: the lower bound it starts from is).  Only the nearest in front and the others in the
         // program's order measured the same: 165 against 167 Msamples/s on the stress scene.
         uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
-#define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const double te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
+#define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const float te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
         RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)
 #undef RT_WIDE_CE
         auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
@@ -1382,10 +1414,10 @@ RT_UNROLL
           stk[sp * stk_stride] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc);
           sp += 1;
         };
-        if (e3 < RT_INF) push(k3);
-        if (e2 < RT_INF) push(k2);
-        if (e1 < RT_INF) push(k1);
-        if (e0 < RT_INF) {
+        if (e3 < FINF) push(k3);
+        if (e2 < FINF) push(k2);
+        if (e1 < FINF) push(k1);
+        if (e0 < FINF) {
           const uint64_t dsc = desc_of(k0);
           if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
           else { i = (uint32_t)dsc; st = ST_LEAF; }

@@ -130,8 +130,10 @@ def test_folded_table_walk_hands_rays_back_to_the_program_order():
     sec = np.concatenate([rng.uniform(-1000.0, 1000.0, (8000, 3)), rng.normal(size=(8000, 3)), rng.uniform(0, 1, (8000, 1))], axis=1)
     rays = np.concatenate([rt.pixel_center_rays(cam, time=0.2), sec])
     rays[5, 3] = np.inf                                     # a ray that is not finite goes the program's way at once
-    for k, o in enumerate([(3e8, 1e8, -2e8), (-4e9, 10.0, 20.0), (0.0, 6e8, 0.0)]):   # so do rays from too far out for the
-        rays[6 + k, 0:3] = o                                                          # table's pad to cover their rounding
+    # rays from far outside are served by the table all the same (its tests measure from the root box's entry), up to
+    # 1e9 times the section's extent; beyond that they go the program's way too
+    for k, o in enumerate([(3e8, 1e8, -2e8), (-4e13, 10.0, 20.0), (0.0, 6e8, 0.0), (2e6, -3e6, 1e6)]):
+        rays[6 + k, 0:3] = o
         rays[6 + k, 3:6] = np.array([30.0 * k, -20.0, 10.0]) - np.array(o)
     d = rt.flatten(gp, wp, lp)
     whole = H.hostsim_first_hit(d, rays)
