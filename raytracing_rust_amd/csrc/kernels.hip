@@ -1204,9 +1204,12 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want, bool* oom
   return RTX_OK;
 }
 
-static unsigned finish_threshold() {  // survivors k_wf_finish takes over (a multiple of 256); RTX_WF_FINISH overrides for tuning
-  static unsigned v = 0;
-  if (!v) { v = 64 * 1024; if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = (unsigned)x & ~255u; } }
+// Survivors at which a finishing kernel takes over (a multiple of 512); RTX_WF_FINISH overrides for tuning.  A program
+// walked from global memory is finished late: its finishing kernel walks the program in the reference's order, a
+// bounce of which costs more than an iteration over a short queue (stress scene: 65536: 171, 4096: 176 Msamples/s).
+static unsigned finish_threshold(bool head_in_global) {
+  unsigned v = head_in_global ? 4096u : 64u * 1024u;
+  if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = ((unsigned)x + 511u) & ~511u; }
   return v;
 }
 
@@ -1225,6 +1228,7 @@ struct WfPlan {
   // the finishing kernel that walks from LDS, when the world program and the deferred section each fit (else null)
   void (*k_finish_lds)(Scene, rtx_camera_desc, uint32_t, unsigned long long, int, uint32_t, WfCounters*, WfQueue, double*, unsigned long long*) = nullptr;
   size_t finish_lds_bytes = 0;
+  unsigned finish_at = 65536;   // survivors at which the finishing kernel takes over
 };
 
 static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long share) {   // share: camera paths per pipeline of the call
@@ -1324,6 +1328,7 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
       P.finish_lds_bytes = std::max(whole_main, P.tail_bytes);
     }
   }
+  P.finish_at = finish_threshold(sc->dev.head_end != 0 && !P.head_lds);
   const unsigned blocks256 = cap / 256;
   P.trav_blocks = (unsigned)ctx->n_cus;
   P.gen_blocks = std::min(blocks256, (unsigned)ctx->n_cus * 8u);
@@ -1469,9 +1474,9 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
       if (P.k_finish_lds)
-        hipLaunchKernelGGL(P.k_finish_lds, dim3((finish_threshold() + RT_FINISH_THREADS - 1) / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+        hipLaunchKernelGGL(P.k_finish_lds, dim3(P.finish_at / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       else
-        hipLaunchKernelGGL(k_wf_finish, dim3(finish_threshold() / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)finish_threshold(), L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+        hipLaunchKernelGGL(k_wf_finish, dim3(P.finish_at / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipMemcpyAsync(&L.host[r.k & 1], L.c, sizeof(WfCounters), hipMemcpyDeviceToHost, s));
       HIP_TRY(ctx, hipEventRecord(L.ev[r.k & 1], s));
