@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0
 #   Deferred-section stream: index 4 + ray 56 + hit 16 in, hit 16 out, per ray that entered the section.  Shading: 16 B
 #   per entry for the sort, 108 B in for an entry the roulette did not end, then a survivor record 92 B or 24 B of
 #   pixel atomics.  Whole bounce: about 390 B.
-SURVEY_TRAVERSE_BYTES, SURVEY_BOUNCE_BYTES = 80, 328
+APRIORI_TRAVERSE_BYTES, APRIORI_BOUNCE_BYTES = 80, 328
 OWN_TRAVERSE_BYTES, OWN_NEW_PATH_BYTES, OWN_BOUNCE_BYTES = 100, 108, 390
 # Counter-derived constants of the profiled build (rocprofv3 --pmc passes over `RTX_WF_LANES=1 python bench.py --rows 10
 # --steps 1 --warmup 0 --roofline-rows 0 --no-cpu-baseline`, tools/prof_gpu.sh; profiles/README.md names the commit).  Per ray segment of the whole
@@ -129,9 +129,9 @@ def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, tor
     seg, paths, it = float(st["segments"]), float(st["paths"]), max(1, st["iterations"])
     if st["traverse_launches"] == 0:   # the fused pipeline was forced
         ms = st["render_ms"]
-        ach = seg * SURVEY_BOUNCE_BYTES / (ms * 1e-3) / 1e9
+        ach = seg * APRIORI_BOUNCE_BYTES / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_render_fused", "kernel_ms": ms / max(1, st["launches"]), "algorithmic_bytes_per_segment": SURVEY_BOUNCE_BYTES}
+                "kernel": "k_render_fused", "kernel_ms": ms / max(1, st["launches"]), "algorithmic_bytes_per_segment": APRIORI_BOUNCE_BYTES}
     new_frac = paths / seg
     own_trav = OWN_TRAVERSE_BYTES * (1.0 - new_frac) + OWN_NEW_PATH_BYTES * new_frac
     p_drop = st["roulette_drops"] / seg
@@ -139,10 +139,10 @@ def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, tor
     own_shade = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
     # deferred rays are not counted by the library; one ray in nine enters the section in this scene (profiles/README.md)
     kernels = [
-        ("k_wf_traverse<true,false,1,true>", "world program + camera rays", st["traverse_ms"], SURVEY_TRAVERSE_BYTES, own_trav, "k_wf_traverse"),
-        ("k_wf_shade", "shading + compaction", st["shade_ms"], SURVEY_BOUNCE_BYTES - SURVEY_TRAVERSE_BYTES, own_shade, "k_wf_shade"),
-        ("k_wf_stream<true,false,0>", "head section (ground BVH), survivors", st["head_ms"], SURVEY_TRAVERSE_BYTES, 72.0 * (1.0 - new_frac), "k_wf_stream_head"),
-        ("k_wf_stream<true,true,1>", "deferred section (sphere cluster)", st["tail_ms"], SURVEY_TRAVERSE_BYTES / 9.0, 92.0 / 9.0, "k_wf_stream_deferred"),
+        ("k_wf_traverse<true,false,1,true>", "world program + camera rays", st["traverse_ms"], APRIORI_TRAVERSE_BYTES, own_trav, "k_wf_traverse"),
+        ("k_wf_shade", "shading + compaction", st["shade_ms"], APRIORI_BOUNCE_BYTES - APRIORI_TRAVERSE_BYTES, own_shade, "k_wf_shade"),
+        ("k_wf_stream<true,false,0>", "head section (ground BVH), survivors", st["head_ms"], APRIORI_TRAVERSE_BYTES, 72.0 * (1.0 - new_frac), "k_wf_stream_head"),
+        ("k_wf_stream<true,true,1>", "deferred section (sphere cluster)", st["tail_ms"], APRIORI_TRAVERSE_BYTES / 9.0, 92.0 / 9.0, "k_wf_stream_deferred"),
     ]
     total_ms = sum(k[2] for k in kernels)
     out = []
@@ -172,8 +172,8 @@ def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, tor
                  "Msegments_per_s": seg_s / 1e6, "Msamples_per_s": paths / (wall_ms * 1e-3) / 1e6},
         "other_kernels": out[1:],
         "whole_bounce": {"note": "all kernels of a bounce over the WALL time of the timed region (all pipelines)",
-                         "algorithmic_bytes_per_segment": SURVEY_BOUNCE_BYTES,
-                         "achieved": wall_seg_per_s * SURVEY_BOUNCE_BYTES / 1e9, "frac": wall_seg_per_s * SURVEY_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_segment": APRIORI_BOUNCE_BYTES,
+                         "achieved": wall_seg_per_s * APRIORI_BOUNCE_BYTES / 1e9, "frac": wall_seg_per_s * APRIORI_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,
                          "own_bytes_per_segment": OWN_BOUNCE_BYTES,
                          "achieved_own_bytes": wall_seg_per_s * OWN_BOUNCE_BYTES / 1e9, "frac_own_bytes": wall_seg_per_s * OWN_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,
                          "unit": "GB/s"},
