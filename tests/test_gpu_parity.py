@@ -105,6 +105,27 @@ def test_gpu_matches_host_build_of_same_code(gpu_ctx, name, width, spp, depth):
     scene.close()
 
 
+def test_gpu_matches_host_build_on_a_scene_walked_from_global_memory(gpu_ctx):
+    """The same comparison on the stress scene at 200 000 primitives: its BVH does not fit LDS, so the GPU's default
+    pipeline walks it over the folded table (single-precision culling, exact leaf boxes, every lane a step per trip)
+    while the host build walks the program itself in the reference's order.  Same paths, hence the same tolerance; 64
+    light quads make every diffuse bounce evaluate 64 light pdfs (hittable_list.rs:78-97)."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("stress", gp, width=96, spp=16, depth=20, n_prims=200000)
+    desc = rt.flatten(gp, wp, lp)
+    scene = rt.Scene(gpu_ctx, desc)
+    gpu_ctx.reset_stats()
+    a = scene.render(cam, rt.render_opts(cam, seed=12))
+    st = gpu_ctx.stats()
+    b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, seed=12))
+    assert st["paths"] == cb["paths"] == 96 * cam.image_height * cam.sqrt_spp ** 2 and st["head_launches"] > 0
+    assert abs(st["segments"] - cb["segments"]) <= 0.002 * cb["segments"]
+    close = np.isclose(a, b, rtol=1e-6, atol=1e-9)
+    assert close.mean() > 0.995, f"stress: only {close.mean():.4f} of the channels agree"
+    assert b.sum() > 0 and abs(a.sum() - b.sum()) < 2e-3 * b.sum()
+    scene.close()
+
+
 def test_texture_probe_first_bounce_matches_oracle(gpu_ctx):
     """Checker (checker.rs:41-56), a checker of a checker with noise and image children, marble noise at two scales
     (texture/noise.rs:29-35), the earth image, a missing image (cyan) - each as the emission of a light, rendered with
