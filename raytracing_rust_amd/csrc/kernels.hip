@@ -759,11 +759,13 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
 }
 
 // The same tail of a call for a program whose world program and deferred section each fit LDS: a workgroup keeps its
-// 512 survivors to their end and walks every bounce from LDS, the world program staged first (a ray that passes the
+// survivors (one per thread) to their end and walks every bounce from LDS, the world program staged first (a ray that passes the
 // deferred section's root box is noted, as in the wavefront traversal) and the deferred section's program after it for
 // the rays noted - the walk of world.hit cut in two, bit for bit.  From global memory a step of the walk costs a round
 // trip to the L2 (k_wf_finish: 220 us per bounce on the final scene); from LDS a third of that.
-#define RT_FINISH_THREADS 512
+#ifndef RT_FINISH_THREADS
+#define RT_FINISH_THREADS 768   // (one workgroup per CU for its LDS: 512: quick 1095, 768: 1135, 1024: 1125 Msamples/s - the registers of shading spill, but more paths finish per round)
+#endif
 template <int MM>
 __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
                                                                     int use_lights, uint32_t threshold, WfCounters* c, WfQueue qin,
@@ -1474,7 +1476,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
       if (P.k_finish_lds)
-        hipLaunchKernelGGL(P.k_finish_lds, dim3(P.finish_at / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+        hipLaunchKernelGGL(P.k_finish_lds, dim3((P.finish_at + RT_FINISH_THREADS - 1) / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       else
         hipLaunchKernelGGL(k_wf_finish, dim3(P.finish_at / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       HIP_TRY(ctx, hipGetLastError());
