@@ -85,7 +85,33 @@ struct Counters {
 static thread_local Counters tl_cnt;
 static thread_local bool tl_skip_media = false;  // first-hit AOV mode: media are stochastic, so skipped
 
-static inline double random_double() { return tl_rng->next_double(); }                          // random.rs:10-13
+// Replay mode, for tests that compare single draws with the device code: while a tape is set, random_double()
+// returns the caller's numbers one after the other instead of the generator's, and notes beside each number what it
+// was drawn for (kind | recursion level << 8 | medium number << 20), so that a test can hand the same numbers to code
+// that draws them in another order.
+enum { TAG_OTHER = 0, TAG_CAMERA = 1, TAG_SHADE = 3, TAG_ROULETTE = 4, TAG_SINGLE_INDEX = 5, TAG_MEDIUM = 6 };
+struct Tape {
+  const double* v; size_t n, pos; uint32_t* tags; size_t overrun;
+};
+static thread_local Tape* tl_tape = nullptr;
+static thread_local uint32_t tl_tag = 0;          // kind | level << 8 of the draws being made
+static thread_local std::vector<double>* tl_ray_log = nullptr;   // rays ray_color was called with (7 doubles each)
+static inline uint32_t tape_tag(uint32_t kind) { return (tl_tag & 0xFFF00u) | kind; }
+struct TagScope {                                 // sets the kind of the draws made while it lives
+  uint32_t saved;
+  explicit TagScope(uint32_t kind, uint32_t extra = 0) : saved(tl_tag) { tl_tag = tape_tag(kind) | extra; }
+  ~TagScope() { tl_tag = saved; }
+};
+
+static inline double random_double() {                                                         // random.rs:10-13
+  if (tl_tape) {
+    Tape& t = *tl_tape;
+    if (t.pos >= t.n) { t.overrun++; return 0.5; }
+    if (t.tags) t.tags[t.pos] = tl_tag;
+    return t.v[t.pos++];
+  }
+  return tl_rng->next_double();
+}
 static inline double random_double_range(double mn, double mx) { return mn + (mx - mn) * random_double(); }  // random.rs:16-19
 static inline int random_int_range(int mn, int mx) {                                           // random.rs:22-25 (inclusive)
   int v = mn + (int)std::floor(random_double() * (double)(mx - mn + 1));
@@ -635,7 +661,11 @@ struct HittableList : Hittable {                                            // g
   }
   Vec3 random(const Point3& origin) const override {                        // 90-97
     if (objects.empty()) return Vec3(1.0, 0.0, 0.0);
-    int idx = random_int_range(0, (int)objects.size() - 1);
+    int idx;
+    {
+      TagScope tag(objects.size() == 1 ? (uint32_t)TAG_SINGLE_INDEX : (tl_tag & 0xFFu));   // a draw with one possible outcome
+      idx = random_int_range(0, (int)objects.size() - 1);
+    }
     return objects[(size_t)idx]->random(origin);
   }
 };
@@ -753,6 +783,7 @@ struct BvhNode : Hittable {                                                 // a
 
 struct ConstantMedium : Hittable {                                          // volumes/constant_medium.rs
   HittablePtr boundary; MaterialPtr phase_function; double neg_inv_density;
+  uint32_t medium_seq = 0;                                                  // number of this medium in its session (replay tags)
   ConstantMedium(HittablePtr b, double density, MaterialPtr iso) : boundary(b), phase_function(iso), neg_inv_density(-1.0 / density) {}
   bool hit(const Ray& r, Interval ray_t, HitRecord& rec) const override {   // 42-90
     if (tl_skip_media) return false;
@@ -765,7 +796,9 @@ struct ConstantMedium : Hittable {                                          // v
     rec1.t = std::fmax(rec1.t, 0.0);
     double ray_length = norm(r.dir);
     double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
-    double hit_distance = neg_inv_density * std::log(random_double());
+    double xi;
+    { TagScope tag(TAG_MEDIUM, medium_seq << 20); xi = random_double(); }
+    double hit_distance = neg_inv_density * std::log(xi);
     if (hit_distance > distance_inside_boundary) return false;
     rec.t = rec1.t + hit_distance / ray_length;
     rec.p = r.at(rec.t);
@@ -860,6 +893,8 @@ static Color ray_color(const CameraDesc& cam, const Ray& r, int depth, const Hit
   if (depth <= 0) return Color(0, 0, 0);
   HitRecord rec;
   tl_cnt.segments++;
+  if (tl_ray_log) { const double f[7] = {r.orig.x, r.orig.y, r.orig.z, r.dir.x, r.dir.y, r.dir.z, r.time}; tl_ray_log->insert(tl_ray_log->end(), f, f + 7); }
+  tl_tag = (uint32_t)TAG_SHADE | ((uint32_t)(cam.max_depth - depth) << 8);   // replay tags only: no effect on the result
   if (!world->hit(r, Interval(0.001, kInf), rec)) return V(cam.background);
   Color emission = rec.mat->emitted(rec.u, rec.v, rec.p);
   ScatterRecord srec;
@@ -880,7 +915,9 @@ static Color ray_color(const CameraDesc& cam, const Ray& r, int depth, const Hit
   double scattering_pdf = rec.mat->scattering_pdf(r, rec, scattered);
   if (depth > 3) {
     double rr_prob = 0.8;
-    if (random_double() > rr_prob) return emission;
+    double rr_draw;
+    { TagScope tag(TAG_ROULETTE); rr_draw = random_double(); }
+    if (rr_draw > rr_prob) return emission;
     double rr_scale = 1.0 / rr_prob;
     return emission + rr_scale * component_mul(srec.attenuation, scattering_pdf * ray_color(cam, scattered, depth - 1, world, lights)) / pdf_value;
   }
@@ -892,7 +929,7 @@ struct Session {
   std::vector<TexturePtr> textures;
   std::vector<MaterialPtr> materials;
   std::vector<HittablePtr> hittables;
-  uint32_t next_prim = 0;
+  uint32_t next_prim = 0, next_medium = 0;
   std::string error;
   int add_tex(TexturePtr t) { textures.push_back(t); return (int)textures.size() - 1; }
   int add_mat(MaterialPtr m) { m->mat_id = (uint32_t)materials.size(); materials.push_back(m); return (int)materials.size() - 1; }
@@ -1010,7 +1047,9 @@ int orc_medium(void* s_, int boundary, double density, int tex) {           // c
   Session* s = (Session*)s_; if (!s->ok_hit(boundary) || !s->ok_tex(tex)) return -1;
   auto iso = std::make_shared<Isotropic>(s->textures[(size_t)tex]);
   s->add_mat(iso);
-  return s->add_hit(std::make_shared<ConstantMedium>(s->hittables[(size_t)boundary], density, iso));
+  auto medium = std::make_shared<ConstantMedium>(s->hittables[(size_t)boundary], density, iso);
+  medium->medium_seq = s->next_medium++;
+  return s->add_hit(medium);
 }
 
 // Bounding box of any hittable (6 doubles: xmin xmax ymin ymax zmin zmax); returns 0 when it has none.
@@ -1087,6 +1126,55 @@ int orc_mat_scatter(void* s_, int mat, const double* dir_in, const double* p, co
   S(atten, srec.attenuation);
   if (srec.skip_pdf) { S(out_dir, srec.skip_pdf_ray.dir); return 1; }
   return 2;
+}
+
+// ---- replay probes: the caller's numbers in place of the generator (see Tape above) ----
+// One camera path: get_ray for (i, j, sample_idx) when ray7 is null, else ray_color on the given ray (orig, dir,
+// time).  tags (n_tape entries, may be null) receives what each consumed number was drawn for; rays_out (7 doubles
+// per call of ray_color that traced a segment, at most max_rays of them) the rays of the path in order.  Returns the
+// number of draws asked for beyond the tape's end (0 = the tape sufficed), -1 on a bad handle.
+long orc_tape_path(void* s_, int world, int lights, const CameraDesc* cam, int i, int j, int sample_idx, const double* ray7,
+                   const double* tape, size_t n_tape, uint32_t* tags, size_t* consumed, double* rays_out, size_t max_rays,
+                   size_t* n_rays, double* color) {
+  Session* s = (Session*)s_; if (!s->ok_hit(world)) return -1;
+  if (lights >= 0 && !s->ok_hit(lights)) return -1;
+  const Hittable* w = s->hittables[(size_t)world].get();
+  const Hittable* l = lights >= 0 ? s->hittables[(size_t)lights].get() : nullptr;
+  Tape t{tape, n_tape, 0, tags, 0};
+  std::vector<double> log;
+  tl_tape = &t; tl_ray_log = &log; tl_tag = TAG_CAMERA;
+  Ray ray;
+  if (ray7) ray = Ray(Point3(ray7[0], ray7[1], ray7[2]), Vec3(ray7[3], ray7[4], ray7[5]), ray7[6]);
+  else ray = camera_get_ray(*cam, i, j, sample_idx / cam->sqrt_spp, sample_idx % cam->sqrt_spp);   // camera.rs:262-264
+  Color c = ray_color(*cam, ray, cam->max_depth, w, l);
+  tl_tape = nullptr; tl_ray_log = nullptr; tl_tag = 0;
+  if (consumed) *consumed = t.pos;
+  const size_t nr = log.size() / 7;
+  if (n_rays) *n_rays = nr;
+  if (rays_out) std::memcpy(rays_out, log.data(), sizeof(double) * 7 * std::min(nr, max_rays));
+  if (color) S(color, c);
+  return (long)t.overrun;
+}
+// The random vectors of math/vec3.rs from a tape: kind 0 random_in_unit_sphere, 1 random_unit_vector,
+// 2 random_cosine_direction, 3 random_in_unit_disk.
+long orc_tape_vec(int kind, const double* tape, size_t n_tape, double* out3, size_t* consumed) {
+  Tape t{tape, n_tape, 0, nullptr, 0};
+  tl_tape = &t;
+  Vec3 v = kind == 0 ? random_in_unit_sphere() : kind == 1 ? random_unit_vector() : kind == 2 ? random_cosine_direction() : random_in_unit_disk();
+  tl_tape = nullptr;
+  S(out3, v);
+  if (consumed) *consumed = t.pos;
+  return (long)t.overrun;
+}
+// Hittable::random(origin) from a tape (hittable_list.rs:90-97, quad.rs:118-121, sphere.rs:143-150).
+long orc_tape_random(void* s_, int obj, const double* origin, const double* tape, size_t n_tape, uint32_t* tags, double* out3, size_t* consumed) {
+  Session* s = (Session*)s_; if (!s->ok_hit(obj)) return -1;
+  Tape t{tape, n_tape, 0, tags, 0};
+  tl_tape = &t; tl_tag = TAG_SHADE;
+  S(out3, s->hittables[(size_t)obj]->random(V(origin)));
+  tl_tape = nullptr; tl_tag = 0;
+  if (consumed) *consumed = t.pos;
+  return (long)t.overrun;
 }
 
 struct RenderOpts {

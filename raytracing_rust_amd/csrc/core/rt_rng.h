@@ -56,12 +56,38 @@ RT_HD PathRng rng_make(uint64_t seed, uint32_t pixel, uint32_t sample) {
 }
 RT_HD void rng_stream(PathRng& r, uint32_t bounce, uint32_t domain) { r.stream = bounce | (domain << 16); r.n = 0; }
 
+// Test-only replay (a host build may define RT_RNG_TAPE; the product never does): while a tape is set, the draws of
+// the camera and shading streams come from the caller's numbers one after the other, the roulette draw of a bounce and
+// the free-path draw of a medium from tables indexed the way those draws are addressed (bounce; bounce and medium).
+#if defined(RT_RNG_TAPE) && !defined(__HIPCC__)
+struct RngTape {
+  const double* seq; size_t n_seq, pos, overrun;
+  const double* roulette; uint32_t n_bounces;      // [bounce]
+  const double* medium; uint32_t n_media;          // [bounce * n_media + medium]
+};
+inline thread_local RngTape* rt_rng_tape = nullptr;
+inline double rng_tape_next() {
+  RngTape& t = *rt_rng_tape;
+  if (t.pos >= t.n_seq) { t.overrun++; return 0.5; }
+  return t.seq[t.pos++];
+}
+#define RT_RNG_TAPE_ACTIVE (rt_rng_tape != nullptr)
+#else
+#define RT_RNG_TAPE_ACTIVE false
+#endif
+
 RT_HD double rng_next(PathRng& r) {  // random_double(), random.rs:10-13
+#if defined(RT_RNG_TAPE) && !defined(__HIPCC__)
+  if (RT_RNG_TAPE_ACTIVE) return rng_tape_next();
+#endif
   uint32_t o[4];
   philox4x32(r.n++, r.stream, r.sample, r.pixel, r.k0, r.k1, o);
   return u53(o[0], o[1]);
 }
 RT_HD void rng_next2(PathRng& r, double& a, double& b) {  // two draws from one block
+#if defined(RT_RNG_TAPE) && !defined(__HIPCC__)
+  if (RT_RNG_TAPE_ACTIVE) { a = rng_tape_next(); b = rng_tape_next(); return; }
+#endif
   uint32_t o[4];
   philox4x32(r.n++, r.stream, r.sample, r.pixel, r.k0, r.k1, o);
   a = u53(o[0], o[1]);
@@ -69,6 +95,14 @@ RT_HD void rng_next2(PathRng& r, double& a, double& b) {  // two draws from one 
 }
 // One draw addressed by an explicit counter (used for media met during traversal: counter = node index).
 RT_HD double rng_at(const PathRng& r, uint32_t stream, uint32_t n) {
+#if defined(RT_RNG_TAPE) && !defined(__HIPCC__)
+  if (RT_RNG_TAPE_ACTIVE && (stream >> 16) == RNG_DOMAIN_MEDIUM) {
+    const uint32_t bounce = stream & 0xFFFFu;
+    if (bounce < rt_rng_tape->n_bounces && n < rt_rng_tape->n_media) return rt_rng_tape->medium[(size_t)bounce * rt_rng_tape->n_media + n];
+    rt_rng_tape->overrun++;
+    return 0.5;
+  }
+#endif
   uint32_t o[4];
   philox4x32(n, stream, r.sample, r.pixel, r.k0, r.k1, o);
   return u53(o[0], o[1]);

@@ -232,6 +232,13 @@ RT_HD double schlick(double cosine, double ratio) {
 // stream.  A function of the path's coordinates only, so the wavefront shading kernel can evaluate it ahead of
 // shade_bounce and drop the paths it ends.
 RT_HD double shade_roulette_draw(PathRng rng, uint32_t bounce) {
+#if defined(RT_RNG_TAPE) && !defined(__HIPCC__)
+  if (RT_RNG_TAPE_ACTIVE) {
+    if (bounce < rt_rng_tape->n_bounces) return rt_rng_tape->roulette[bounce];
+    rt_rng_tape->overrun++;
+    return 0.5;
+  }
+#endif
   rng_stream(rng, bounce, RNG_DOMAIN_SHADE);
   return rng_next(rng);
 }
@@ -372,11 +379,14 @@ RT_HD Ray camera_ray(const rtx_camera_desc& c, int i, int j, int sample_idx, Pat
   return r;
 }
 
-// One whole camera path (calculate_pixel_color's closure body, camera.rs:261-266).
-RT_HD V3 trace_path(const Scene& S, const rtx_camera_desc& cam, bool use_lights, int i, int j, int sample_idx,
-                    uint64_t seed, uint32_t& segments, uint32_t& probes) {
-  PathRng rng = rng_make(seed, (uint32_t)(j * cam.image_width + i), (uint32_t)sample_idx);
-  Ray ray = camera_ray(cam, i, j, sample_idx, rng);
+// Test-only hook: a build may define RT_TRACE_RAY(ray) to record the ray of every segment of a path.
+#ifndef RT_TRACE_RAY
+#define RT_TRACE_RAY(ray) ((void)0)
+#endif
+
+// ray_color on one ray (camera.rs:167-247) as a loop over bounces.
+RT_HD V3 trace_ray(const Scene& S, const rtx_camera_desc& cam, bool use_lights, Ray ray, const PathRng& rng,
+                   uint32_t& segments, uint32_t& probes) {
   PathState ps;
   path_begin(ps, cam.max_depth, rng);
   const V3 bg = v3(cam.background);
@@ -385,6 +395,7 @@ RT_HD V3 trace_path(const Scene& S, const rtx_camera_desc& cam, bool use_lights,
     Hit hit;
     double stale_uv[2] = {0.0, 0.0};
     ++segments;
+    RT_TRACE_RAY(ray);
     RayRegs rs;
     rs.r = ray;
     closest_hit<true>(S, S.prog, S.world_begin, true, rs, ray.tm, 0.001, RT_INF, hit, true, ps.rng, ps.bounce, stale_uv);
@@ -393,6 +404,14 @@ RT_HD V3 trace_path(const Scene& S, const rtx_camera_desc& cam, bool use_lights,
     ray = next;
   }
   return ps.L;
+}
+
+// One whole camera path (calculate_pixel_color's closure body, camera.rs:261-266).
+RT_HD V3 trace_path(const Scene& S, const rtx_camera_desc& cam, bool use_lights, int i, int j, int sample_idx,
+                    uint64_t seed, uint32_t& segments, uint32_t& probes) {
+  PathRng rng = rng_make(seed, (uint32_t)(j * cam.image_width + i), (uint32_t)sample_idx);
+  Ray ray = camera_ray(cam, i, j, sample_idx, rng);
+  return trace_ray(S, cam, use_lights, ray, rng, segments, probes);
 }
 
 // color_to_rgb_with_samples, rendering/color.rs:7-52, one channel.

@@ -8,6 +8,11 @@
 static thread_local uint8_t* g_trace = nullptr;
 static thread_local uint32_t g_trace_len = 0, g_trace_cap = 0;
 #define RT_TRACE_STEP(kind) do { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = (uint8_t)(kind); } while (0)
+// ray log of the replay probes (sim_tape_path): the ray of every segment of a path, in order
+#include <vector>
+static thread_local std::vector<double>* g_ray_log = nullptr;
+#define RT_TRACE_RAY(ray) do { if (g_ray_log) { const double f_[7] = {(ray).o.x, (ray).o.y, (ray).o.z, (ray).d.x, (ray).d.y, (ray).d.z, (ray).tm}; g_ray_log->insert(g_ray_log->end(), f_, f_ + 7); } } while (0)
+#define RT_RNG_TAPE 1   // the device core's draws can be replayed from a caller's numbers (rt_rng.h)
 #include <atomic>
 #include <thread>
 #include <functional>
@@ -334,6 +339,69 @@ void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_
     V3 d = lights_random(*S, v3(origin), r);
     out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
   }
+}
+// ---- replay probes: the caller's numbers in place of the path RNG (RngTape, rt_rng.h) ----
+// One camera path of the device core: camera_ray for (i, j, sample_idx) when ray7 is null, else trace_ray on the given
+// ray.  seq: the numbers of the camera and shading draws in the order the device core makes them; roulette: one
+// number per bounce; medium: n_bounces x n_media numbers.  rays_out: the ray of every segment (7 doubles each, at
+// most max_rays).  Returns the number of draws asked for beyond what was supplied.
+struct SimScene { CompiledProgram prog; Scene view; };
+void* sim_scene_new(const rtx_scene_desc* desc) {      // the compiled program of a description, kept for many probe calls
+  SimScene* h = new SimScene();
+  h->prog.fuse_sphere_media = g_fuse_sphere_media; h->prog.defer_last_section = g_defer_last_section; h->prog.guard_box6 = g_guard_box6;
+  h->prog.compile(*desc);
+  h->view = h->prog.host_view(*desc);
+  return h;
+}
+void sim_scene_free(void* h) { delete (SimScene*)h; }
+long sim_tape_path(void* scene, const rtx_camera_desc* cam, int use_lights, int i, int j, int sample_idx,
+                   const double* ray7, const double* seq, size_t n_seq, const double* roulette, uint32_t n_bounces,
+                   const double* medium, uint32_t n_media, size_t* consumed, double* rays_out, size_t max_rays,
+                   size_t* n_rays, double* color, uint32_t* counters) {
+  const Scene& S = ((SimScene*)scene)->view;
+  RngTape tape{seq, n_seq, 0, 0, roulette, n_bounces, medium, n_media};
+  std::vector<double> log;
+  rt_rng_tape = &tape; g_ray_log = &log;
+  PathRng rng = rng_make(1, 0, 0);
+  Ray ray;
+  if (ray7) { ray.o = v3(ray7[0], ray7[1], ray7[2]); ray.d = v3(ray7[3], ray7[4], ray7[5]); ray.tm = ray7[6]; }
+  else ray = camera_ray(*cam, i, j, sample_idx, rng);
+  uint32_t sg = 0, pb = 0;
+  const V3 c = trace_ray(S, *cam, use_lights != 0 && S.has_lights != 0, ray, rng, sg, pb);
+  rt_rng_tape = nullptr; g_ray_log = nullptr;
+  if (consumed) *consumed = tape.pos;
+  const size_t nr = log.size() / 7;
+  if (n_rays) *n_rays = nr;
+  if (rays_out) memcpy(rays_out, log.data(), sizeof(double) * 7 * std::min(nr, max_rays));
+  if (color) { color[0] = c.x; color[1] = c.y; color[2] = c.z; }
+  if (counters) { counters[0] = sg; counters[1] = pb; }
+  return (long)tape.overrun;
+}
+// The random vectors of rt_rng.h from a tape: kind 0 random_in_unit_sphere, 1 random_unit_vector,
+// 2 random_cosine_direction, 3 random_in_unit_disk.
+long sim_tape_vec(int kind, const double* seq, size_t n_seq, double* out3, size_t* consumed) {
+  RngTape tape{seq, n_seq, 0, 0, nullptr, 0, nullptr, 0};
+  rt_rng_tape = &tape;
+  PathRng rng = rng_make(1, 0, 0);
+  const V3 v = kind == 0 ? random_in_unit_sphere(rng) : kind == 1 ? random_unit_vector(rng) : kind == 2 ? random_cosine_direction(rng) : random_in_unit_disk(rng);
+  rt_rng_tape = nullptr;
+  out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
+  if (consumed) *consumed = tape.pos;
+  return (long)tape.overrun;
+}
+// lights_random(origin) from a tape.
+long sim_tape_lights_random(const rtx_scene_desc* desc, const double* origin, const double* seq, size_t n_seq, double* out3, size_t* consumed) {
+  CompiledProgram prog;
+  prog.compile(*desc);
+  const Scene S = prog.host_view(*desc);
+  RngTape tape{seq, n_seq, 0, 0, nullptr, 0, nullptr, 0};
+  rt_rng_tape = &tape;
+  PathRng rng = rng_make(1, 0, 0);
+  const V3 v = lights_random(S, v3(origin), rng);
+  rt_rng_tape = nullptr;
+  out3[0] = v.x; out3[1] = v.y; out3[2] = v.z;
+  if (consumed) *consumed = tape.pos;
+  return (long)tape.overrun;
 }
 void sim_camera_ray(const rtx_camera_desc* cam, int i, int j, int sample_idx, uint64_t seed, double* out7) {
   PathRng r = rng_make(seed, (uint32_t)(j * cam->image_width + i), (uint32_t)sample_idx);

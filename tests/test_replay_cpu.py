@@ -1,0 +1,198 @@
+"""CPU tier: everything that consumes random numbers, device core against oracle VALUE BY VALUE.  The same numbers are
+fed to both in place of their generators (tests/replay.py); both run on the host with the same libm, so even the
+routines that call sin, cos and ln must agree to the last bit (the tests allow 2 units in the last place there).
+
+Covers Metal::scatter (metal.rs:24-38), Dielectric::scatter with total internal reflection, Schlick and refract
+(dielectric.rs:23-55, vec3.rs:76-85), the rejection loops of vec3.rs:31-61, random_cosine_direction (vec3.rs:63-73),
+Quad::random and Sphere::random (quad.rs:118-121, sphere.rs:69-79,143-150), the list's index draw
+(hittable_list.rs:90-97), the mixture's coin (mixture_pdf.rs:45-52), the medium's free path (constant_medium.rs:74-81),
+the roulette (camera.rs:227-231) and get_ray with and without a lens (camera.rs:133-164)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import raytracing_rust_amd as rt
+from raytracing_rust_amd import scenes
+import helpers as H
+import replay as R
+
+
+@pytest.mark.parametrize("kind,name,transcendental", [(0, "random_in_unit_sphere", False), (1, "random_unit_vector", False),
+                                                      (2, "random_cosine_direction", True), (3, "random_in_unit_disk", False)])
+def test_random_vectors_replayed(kind, name, transcendental):
+    R._bind()
+    rng = np.random.default_rng(40 + kind)
+    tapes = [rng.uniform(0, 1, 64) for _ in range(2000)]
+    # rejection loops: first candidates outside the unit ball / disk, then one inside; a candidate ON the sphere
+    tapes += [np.array([0.99, 0.98, 0.97, 0.01, 0.02, 0.99, 0.4, 0.5, 0.6] + [0.5] * 8),
+              np.array([1.0 - 2.0 ** -53, 0.5, 0.5, 0.5, 0.5, 0.5] + [0.25] * 8),
+              np.array([0.0, 0.0, 0.0, 0.5, 0.5, 0.5, 0.75, 0.5, 0.5] + [0.25] * 8)]
+    rejected = 0
+    for t in tapes:
+        t = np.ascontiguousarray(t)
+        a, b = np.zeros(3), np.zeros(3)
+        ca, cb = C.c_size_t(0), C.c_size_t(0)
+        assert H.oracle_lib().orc_tape_vec(kind, H.dptr(t), len(t), H.dptr(a), C.byref(ca)) == 0
+        assert H.hostsim_lib().sim_tape_vec(kind, H.dptr(t), len(t), H.dptr(b), C.byref(cb)) == 0
+        assert ca.value == cb.value, f"{name}: {ca.value} draws in the oracle, {cb.value} in the device core"
+        rejected += ca.value > (2 if kind >= 2 else 3)
+        if transcendental:
+            assert R.ulp_distance(a, b).max() <= 2, (name, a, b)
+        else:
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (name, a, b)
+    if kind != 2:
+        assert rejected > 100          # the loops did loop
+
+
+@pytest.mark.parametrize("name", ["cornell", "final"])
+def test_light_sampling_replayed(name):
+    """lights.random(origin): the index draw (hittable_list.rs:94), Quad::random (quad.rs:118-121) bit for bit,
+    Sphere::random (sphere.rs:143-150; sin, cos) within 2 units in the last place.  cornell: a quad and a sphere;
+    final: one quad (the reference still draws an index, the device core does not)."""
+    R._bind()
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam = scenes.build(name, go, width=64, prefix="orc_", lib=H.oracle_lib())
+    wp, lp, _ = scenes.build(name, gp, width=64)
+    desc = rt.flatten(gp, wp, lp)
+    rng = np.random.default_rng(11)
+    picked_sphere = 0
+    for _ in range(1500):
+        origin = rng.uniform(20, 530, 3)
+        tape = rng.uniform(0, 1, 16)
+        tags = np.zeros(16, dtype=np.uint32)
+        a, b = np.zeros(3), np.zeros(3)
+        ca, cb = C.c_size_t(0), C.c_size_t(0)
+        assert H.oracle_lib().orc_tape_random(go.session, lo, H.dptr(origin), H.dptr(tape), 16, tags.ctypes.data_as(H.PU32), H.dptr(a), C.byref(ca)) == 0
+        seq = np.ascontiguousarray(tape[:ca.value][(tags[:ca.value] & 0xFF) != R.TAG_SINGLE_INDEX])
+        assert H.hostsim_lib().sim_tape_lights_random(C.byref(desc), H.dptr(origin), H.dptr(seq), len(seq), H.dptr(b), C.byref(cb)) == 0
+        assert cb.value == len(seq)
+        sphere = name == "cornell" and tape[0] >= 0.5       # the second light of the list is the glass sphere
+        picked_sphere += sphere
+        if sphere:
+            assert R.ulp_distance(a, b).max() <= 2, (origin, a, b)
+        else:
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (origin, a, b)
+    assert (picked_sphere > 500) == (name == "cornell")
+
+
+def _both(name, **kw):
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam = scenes.build(name, go, prefix="orc_", lib=H.oracle_lib(), **kw)
+    wp, lp, _ = scenes.build(name, gp, **kw)
+    desc = rt.flatten(gp, wp, lp)
+    return go, wo, lo, R.DeviceScene(desc, keep=gp), cam, desc
+
+
+@pytest.mark.parametrize("name,width,depth,n_paths", [("cornell", 48, 50, 1200), ("smoke", 48, 50, 800), ("final", 64, 75, 1500),
+                                                      ("final", 64, 3, 600)])
+def test_whole_paths_replayed(name, width, depth, n_paths):
+    """Camera paths of the shipped scenes, ray_color of the oracle (recursion, camera.rs:167-247) against the device
+    core's loop with the same numbers: the same rays bit for bit at every bounce - which pins every scatter, every
+    sampled direction, every pdf rejection, every free path and the roulette - and the same radiance to 1e-12."""
+    go, wo, lo, dev, cam, desc = _both(name, width=width, spp=16, depth=depth)
+    rng = np.random.default_rng(77)
+    kinds = np.zeros(8, dtype=np.int64)
+    segments = 0
+    longest = 0
+    for _ in range(n_paths):
+        pixel = (int(rng.integers(cam.image_width)), int(rng.integers(cam.image_height)), int(rng.integers(16)))
+        a, b = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, pixel=pixel)
+        kinds += np.bincount(a["tags"] & 0xFF, minlength=8)[:8]
+        segments += len(a["rays"])
+        longest = max(longest, len(a["rays"]))
+    assert segments > 2 * n_paths and longest >= min(depth, 8)
+    assert kinds[R.TAG_CAMERA] == 3 * n_paths and kinds[R.TAG_SHADE] > 2 * n_paths
+    if depth > 3:
+        assert kinds[R.TAG_ROULETTE] > n_paths // 2
+    if name in ("smoke", "final"):
+        assert kinds[R.TAG_MEDIUM] > n_paths // 4
+    if name in ("smoke", "final"):
+        assert kinds[R.TAG_SINGLE_INDEX] > n_paths // 4         # one light in the list
+
+
+def probe_scene(g):
+    """Every material under a sphere light and a quad light, with a medium: metal with and without fuzz, glass (hit from
+    outside and, by rays that start inside it, from inside at angles beyond the critical one), Lambertian, a
+    box-bounded and a sphere-bounded medium, a moving sphere."""
+    red, white = g.lambertian_color(0.65, 0.05, 0.05), g.lambertian_color(0.73, 0.73, 0.73)
+    light = g.diffuse_light_color(9, 8, 7)
+    floor = g.quad((-60, 0, -60), (120, 0, 0), (0, 0, 120), white)
+    back = g.quad((-60, 0, -60), (120, 0, 0), (0, 80, 0), red)
+    metal = g.sphere((-25, 10, 0), 10.0, g.metal(0.8, 0.85, 0.88, 0.0))
+    fuzzy = g.sphere((25, 10, 0), 10.0, g.metal(0.7, 0.6, 0.5, 0.6))
+    glass = g.sphere((0, 12, 10), 12.0, g.dielectric(1.5))
+    mover = g.sphere_moving((0, 30, -20), (0, 36, -20), 5.0, white)
+    smoke = g.medium(g.translate(g.rotate_y(g.box((0, 0, 0), (16, 16, 16), white), 25.0), (-20, 0, 25)), 0.08, g.solid(0.9, 0.9, 0.9))
+    haze = g.medium(g.sphere((20, 8, 28), 8.0, white), 0.15, g.solid(0.2, 0.4, 0.9))
+    quad_light = g.quad((-15, 70, -15), (30, 0, 0), (0, 0, 30), light)
+    sphere_light = g.sphere((45, 45, 20), 6.0, light)
+    world = g.list([floor, back, metal, fuzzy, glass, mover, smoke, haze, quad_light, sphere_light])
+    lights = g.list([g.quad((-15, 70, -15), (30, 0, 0), (0, 0, 30), g.none()), g.sphere((45, 45, 20), 6.0, g.none())])
+    cam = dict(aspect_ratio=1.0, image_width=64, samples_per_pixel=16, max_depth=12, background=(0.02, 0.03, 0.05),
+               vfov=55.0, lookfrom=(0.0, 35.0, 110.0), lookat=(0.0, 15.0, 0.0))
+    return world, lights, cam
+
+
+def _probe_both(**cam_over):
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, camkw = probe_scene(go)
+    wp, lp, _ = probe_scene(gp)
+    camkw.update(cam_over)
+    cam = rt.initialize_camera(rt.camera_desc(**camkw))
+    desc = rt.flatten(gp, wp, lp)
+    return go, wo, lo, R.DeviceScene(desc, keep=gp), cam, desc
+
+
+def test_materials_replayed_on_probe_scene():
+    go, wo, lo, dev, cam, desc = _probe_both()
+    assert desc.n_media == 2
+    rng = np.random.default_rng(5)
+    n = 0
+    for _ in range(1500):                                   # camera paths
+        pixel = (int(rng.integers(64)), int(rng.integers(64)), int(rng.integers(16)))
+        a, _ = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, pixel=pixel)
+        n += len(a["rays"])
+    assert n > 2500
+    # rays aimed at each object in turn (scatter of the first bounce = a function-level probe of its material)
+    targets = {"metal": ((-25, 10, 0), 9.0), "fuzzy": ((25, 10, 0), 9.0), "glass": ((0, 12, 10), 11.0), "mover": ((0, 33, -20), 4.0),
+               "smoke": ((-12, 8, 33), 6.0), "haze": ((20, 8, 28), 6.0)}
+    for what, (c, r) in targets.items():
+        went_on = 0
+        for _ in range(300):
+            o = np.array([0.0, 35.0, 110.0]) + rng.uniform(-20, 20, 3)
+            d = (np.array(c) + rng.uniform(-r, r, 3) * 0.6 - o) * rng.uniform(0.3, 2.0)
+            a, _ = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, ray=np.array([*o, *d, rng.uniform()]))
+            went_on += len(a["rays"]) > 1
+        assert went_on > 100, what
+    # from inside the glass: directions from near the surface, many beyond the critical angle (total internal reflection
+    # draws nothing: dielectric.rs:42 short-circuits), the rest through Schlick and refract
+    no_draw = 0
+    for _ in range(600):
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        o = np.array([0.0, 12.0, 10.0]) + u * 12.0 * rng.uniform(0.7, 0.98)
+        d = rng.normal(size=3)
+        ray = np.array([*o, *d, 0.3])
+        a, _ = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, ray=ray)
+        first_level = a["tags"][((a["tags"] >> 8) & 0xFFF) == 0]
+        no_draw += len(first_level) == 0 and len(a["rays"]) > 1
+    assert no_draw > 60
+
+
+def test_defocus_camera_replayed():
+    """get_ray with a lens (camera.rs:139-164): defocus angle 2 degrees; the lens point is drawn by rejection from the
+    unit disk between the jitter and the time.  Same rays bit for bit, origins on the lens disk."""
+    go, wo, lo, dev, cam, desc = _probe_both(defocus_angle=2.0, focus_dist=100.0)
+    rng = np.random.default_rng(6)
+    center = np.array(cam.center[:])
+    radius = 100.0 * math.tan(math.radians(1.0))
+    offs = []
+    for _ in range(800):
+        pixel = (int(rng.integers(64)), int(rng.integers(64)), int(rng.integers(16)))
+        a, _ = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, pixel=pixel)
+        n_cam = int(((a["tags"] & 0xFF) == R.TAG_CAMERA).sum())
+        assert n_cam >= 5 and n_cam % 2 == 1                 # jitter x, y; lens candidates in pairs; time
+        offs.append(np.linalg.norm(a["rays"][0, :3] - center))
+    offs = np.array(offs)
+    assert (offs <= radius * (1 + 1e-12)).all() and offs.max() > 0.8 * radius and (offs > 0).all()
