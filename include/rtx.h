@@ -255,7 +255,11 @@ rtx_status rtx_render_device(rtx_scene* scene, const rtx_camera_desc* cam, const
  * rectangle x sample indices - must not exceed RTX_NOALLOC_MAX_PATHS (RTX_ERR_INVALID otherwise; split the rectangle
  * or the sample range).  All such calls on one GPU share that GPU's array: calls of one context are ordered by the
  * library; calls of different contexts (or processes' threads) on the same GPU that overlap in time race and must be
- * ordered by the caller. */
+ * ordered by the caller.  Under stream capture (hipStreamBeginCapture on hip_stream) the call's launches become nodes
+ * of the caller's graph and the library's ordering between calls is left out: launches of that graph are ordered
+ * against other calls of the context by the caller; rtx_stats counts launches at capture time, the device-side
+ * counters (paths, segments, probes) at every replay; the launch plan is the one of the time of capture.
+ * opts->pipeline must be RTX_PIPELINE_DEFAULT or RTX_PIPELINE_WAVEFRONT (RTX_ERR_INVALID otherwise). */
 #define RTX_NOALLOC_MAX_PATHS 65536
 rtx_status rtx_render_device_noalloc(rtx_scene* scene, const rtx_camera_desc* cam, const rtx_render_opts* opts,
                                      double* accum_dev, void* hip_stream);

@@ -1725,9 +1725,15 @@ rtx_status rtx_render_device_noalloc(rtx_scene* sc, const rtx_camera_desc* cam, 
   if (total == 0 || cam->max_depth <= 0) return RTX_OK;   // a path of depth 0 is black (camera.rs:169-171)
   unsigned char* base = (ctx->device >= 0 && ctx->device < RT_MAX_DEVICES) ? g_noalloc_ptr[ctx->device] : nullptr;
   if (!base) return fail(ctx, RTX_ERR_HIP, "rtx_render_device_noalloc: the scratch array of this device was not set up");
+  if (o->pipeline == RTX_PIPELINE_FUSED) return fail(ctx, RTX_ERR_INVALID, "rtx_render_device_noalloc: runs the wavefront pipeline only (opts->pipeline must not be RTX_PIPELINE_FUSED)");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t)hip_stream;
-  HIP_TRY(ctx, call_begin(ctx, stream));
+  // Under stream capture the launches become nodes of the caller's graph: the context's ordering event stays out of it
+  // (recorded inside a capture it would tie later eager calls to that capture), and the caller orders launches of the
+  // graph against other calls of this context.
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(stream, &capture) == hipSuccess && capture == hipStreamCaptureStatusActive;
+  if (!capturing) HIP_TRY(ctx, call_begin(ctx, stream));
   const uint32_t cap = RTX_NOALLOC_MAX_PATHS;
   const WfBuffers B = noalloc_buffers(base);
   const WfPlan P = wf_make_plan(sc, cap, total);
@@ -1743,7 +1749,7 @@ rtx_status rtx_render_device_noalloc(rtx_scene* sc, const rtx_camera_desc* cam, 
   wf_launch_iteration(sc, P, cam, fr, seed, use_lights, B, 0, stream, accum_dev, false);
   hipLaunchKernelGGL(k_wf_finish, dim3(cap / 256), dim3(256), 0, stream, sc->dev, *cam, cap, seed, use_lights, cap, B.c, B.q[1], accum_dev, ctx->d_counters);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, call_end(ctx, stream));
+  if (!capturing) HIP_TRY(ctx, call_end(ctx, stream));
   return RTX_OK;
 }
 

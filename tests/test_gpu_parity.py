@@ -126,6 +126,59 @@ def test_gpu_matches_host_build_on_a_scene_walked_from_global_memory(gpu_ctx):
     scene.close()
 
 
+@pytest.mark.parametrize("depth,defocus", [(2, 0.0), (12, 0.0), (12, 2.0)])
+def test_material_probe_matches_host_build(gpu_ctx, depth, defocus):
+    """Metal with and without fuzz, glass, Lambertian walls, a moving sphere, a box-bounded and a sphere-bounded medium
+    under a quad light and a sphere light (two lights: the index draw of hittable_list.rs:94 and Sphere::random run),
+    at depth 2 (every path is one scatter and one more segment) and depth 12, and through a lens (defocus angle 2
+    degrees, camera.rs:139-164).  The host build of the same code traces the same paths (same RNG addressing); it is
+    compared with the oracle value by value under replayed random numbers on this very scene (CPU tier,
+    test_replay_cpu.py), so this carries that comparison onto the device.  Tolerance as in the test above."""
+    gp = rt.Graph()
+    wp, lp, camkw = recipes.material_probe(gp)
+    camkw.update(max_depth=depth, image_width=96, defocus_angle=defocus, focus_dist=100.0 if defocus else 10.0)
+    cam = rt.initialize_camera(rt.camera_desc(**camkw))
+    desc = rt.flatten(gp, wp, lp)
+    scene = rt.Scene(gpu_ctx, desc)
+    for pipe in (_capi.PIPELINE_WAVEFRONT, _capi.PIPELINE_FUSED):
+        gpu_ctx.reset_stats()
+        a = scene.render(cam, rt.render_opts(cam, seed=13, pipeline=pipe))
+        st = gpu_ctx.stats()
+        b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, seed=13))
+        assert st["paths"] == cb["paths"] == 96 * 96 * 16
+        assert abs(st["segments"] - cb["segments"]) <= 0.002 * cb["segments"] and cb["segments"] > 1.5 * cb["paths"]
+        assert abs(st["pdf_probes"] - cb["pdf_probes"]) <= 0.002 * cb["pdf_probes"] and cb["pdf_probes"] > 0
+        close = np.isclose(a, b, rtol=1e-6, atol=1e-9)
+        assert close.mean() > 0.995, f"only {close.mean():.4f} of the channels agree"
+        assert b.sum() > 0 and abs(a.sum() - b.sum()) < 2e-3 * b.sum()
+    scene.close()
+
+
+def test_stress_scene_render_path_at_full_size(gpu_ctx):
+    """The render path of the stress configuration AT SIZE: 1 M spheres and quads in one BvhNode, 64 lights.  The
+    default (wavefront) pipeline walks that BVH as a stream over the folded table, nearer child first, from global
+    memory; the fused pipeline walks the program in the reference's order.  480 x 270 pixels of the 16:9 camera, 4
+    samples, depth 12: the same segments and light probes, radiance within 1e-11 (order of the f64 additions)."""
+    gp = rt.Graph()
+    gp.use_context(gpu_ctx)
+    wp, lp, cam = scenes.build("stress", gp, width=480, spp=4, depth=12)
+    assert (cam.image_width, cam.image_height) == (480, 270)
+    desc = rt.flatten(gp, wp, lp)
+    assert desc.n_spheres + desc.n_quads == 1000000 and desc.n_lights == 64
+    scene = rt.Scene(gpu_ctx, desc)
+    out = {}
+    for pipe in (_capi.PIPELINE_FUSED, _capi.PIPELINE_WAVEFRONT):
+        gpu_ctx.reset_stats()
+        out[pipe] = (scene.render(cam, rt.render_opts(cam, seed=19, pipeline=pipe)), gpu_ctx.stats())
+    (a, sa), (b, sb) = out[_capi.PIPELINE_FUSED], out[_capi.PIPELINE_WAVEFRONT]
+    assert sa["paths"] == sb["paths"] == 480 * 270 * 4
+    assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"] and sb["head_launches"] > 0
+    assert sb["segments"] > 1.5 * sb["paths"]
+    np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    assert a.sum() > 0
+    scene.close()
+
+
 def test_texture_probe_first_bounce_matches_oracle(gpu_ctx):
     """Checker (checker.rs:41-56), a checker of a checker with noise and image children, marble noise at two scales
     (texture/noise.rs:29-35), the earth image, a missing image (cyan) - each as the emission of a light, rendered with

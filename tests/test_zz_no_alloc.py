@@ -26,12 +26,15 @@ def _both(scene, ctx, cam, opts):
     return a.numpy(), sa, b.numpy(), sb
 
 
-@pytest.mark.parametrize("name,stream", [("final", None), ("final", "1"), ("smoke", None), ("cornell", None)])
+@pytest.mark.parametrize("name,stream", [("final", None), ("final", "1"), ("smoke", None), ("cornell", None), ("stress", None)])
 def test_noalloc_matches_render_device_twice_in_a_row(gpu_ctx, monkeypatch, name, stream):
     if stream is not None:
         monkeypatch.setenv("RTX_WF_STREAM", stream)   # the sections of the final scene as streams too (calls this small walk them per ray)
     g = rt.Graph()
-    w, l, cam = scenes.build(name, g, width=96, spp=16, depth=30)
+    # stress: a head section in global memory, walked over the folded table, no world-program launch, and the whole
+    # queue handed to the finishing kernel that walks from global memory
+    kw = dict(n_prims=200000) if name == "stress" else {}
+    w, l, cam = scenes.build(name, g, width=96 if name != "stress" else 160, spp=16, depth=30, **kw)
     scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
     # first call: exactly the limit (64 x 64 pixels x 16 sample indices); second: a smaller, ragged one
     calls = [rt.render_opts(cam, rect=(8, 8, 72, 72), seed=41), rt.render_opts(cam, sample_begin=3, sample_end=10, rect=(5, 50, 45, 81), seed=42)]
@@ -55,6 +58,11 @@ def test_noalloc_rejects_calls_beyond_its_limit(gpu_ctx):
         scene.render_device_noalloc(cam, rt.render_opts(cam, rect=(8, 8, 73, 72)), acc.ptr)
     assert e.value.status == _capi.RTX_ERR_INVALID and "RTX_NOALLOC_MAX_PATHS" in str(e.value)
     assert not acc.numpy().any()
+    # the fused pipeline is not what this entry point runs: asked for by name, it is refused, not silently replaced
+    with pytest.raises(rt.RtxError) as e:
+        scene.render_device_noalloc(cam, rt.render_opts(cam, rect=(8, 8, 40, 40), pipeline=_capi.PIPELINE_FUSED), acc.ptr)
+    assert e.value.status == _capi.RTX_ERR_INVALID
+    assert not acc.numpy().any()
     scene.close()
 
 
@@ -72,5 +80,40 @@ def test_noalloc_tiles_add_up_to_the_frame(gpu_ctx):
         for x in range(0, 128, 64):
             scene.render_device_noalloc(cam, rt.render_opts(cam, rect=(x, y, x + 64, y + 64), seed=43), tiles.ptr, stream.handle.value)
     np.testing.assert_allclose(tiles.numpy(), full.numpy(), rtol=1e-11, atol=1e-13)
+    stream.close()
+    scene.close()
+
+
+def test_noalloc_calls_captured_into_a_graph(gpu_ctx):
+    """Two calls captured into a HIP graph (nothing runs during capture), the graph launched twice, then an eager call
+    on another stream: the accumulator must hold twice the two calls' result plus the eager one, as rtx_render_device
+    computes them.  The captured calls take no part in the context's ordering between calls, so the test orders the
+    graph launches and the eager call itself (one stream, then a host wait)."""
+    g = rt.Graph()
+    w, l, cam = scenes.build("final", g, width=96, spp=16, depth=30)
+    scene = rt.Scene.from_graph(gpu_ctx, g, w, l)
+    n = cam.image_height * cam.image_width * 3
+    calls = [rt.render_opts(cam, rect=(8, 8, 72, 72), seed=45), rt.render_opts(cam, sample_begin=3, sample_end=10, rect=(5, 50, 45, 81), seed=46)]
+    eager = rt.render_opts(cam, rect=(30, 30, 90, 90), sample_begin=0, sample_end=9, seed=47)
+    want = hiprt.DeviceArray(n)
+    for _ in range(2):
+        for o in calls:
+            scene.render_device(cam, o, want.ptr)
+    scene.render_device(cam, eager, want.ptr)
+    got = hiprt.DeviceArray(n)
+    stream = hiprt.Stream()
+    graph = hiprt.CapturedGraph(stream)
+    with graph:
+        for o in calls:
+            scene.render_device_noalloc(cam, o, got.ptr, stream.handle.value)
+    hiprt.synchronize()
+    assert not got.numpy().any()                # capture ran nothing
+    graph.launch()
+    graph.launch()
+    hiprt.synchronize()
+    scene.render_device_noalloc(cam, eager, got.ptr)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-11, atol=1e-13)
+    assert want.numpy().sum() > 0
+    graph.close()
     stream.close()
     scene.close()
