@@ -8,12 +8,13 @@ every pixel of the 800x800 frame traced for all 70 x 70 = 4900 stratified sample
 `--rows R` renders R of the 70 rows per step instead).
 
 With N > 1 the command starts its own ranks (one process per GPU through torch.distributed.run; the parent process
-never touches a GPU) unless it already runs under a launcher (WORLD_SIZE set).  Two modes are timed, each over K
-steps between barriers, maximum over ranks:
-  weak    (the headline `value`): every (rank, step) renders a whole frame with its own path seed; the ranks'
-          accumulators are summed on rank 0 with one reduce (RCCL) and copied to the host inside the timed region.
-  strong  (`strong_scaling`): ONE frame per step, its 70 rows of the stratification split between the ranks, reduce and
-          copy to the host after every frame: the 800x800x5000spp image on N GPUs.
+never touches a GPU) unless it already runs under a launcher (WORLD_SIZE set).  Modes, each timed over K steps between
+barriers, maximum over ranks:
+  strong  (the headline `value` at every N): ONE frame per step, its sample indices split evenly between the ranks
+          (by index: 4900 over 8 ranks = 613 or 612 each), one reduce(sum) of the f64 accumulators (RCCL) and the copy
+          to the host after every frame, inside the timed region: the 800x800x5000spp image on N GPUs.
+  weak    (`weak_scaling`, N > 1 only): every (rank, step) renders a whole frame with its own path seed; one reduce
+          and copy to the host at the end of the timed region.
 Rank 0 then measures the roofline block (a short single-pipeline render, so that kernels run one at a time and their
 durations are exclusive) and, at N = 1, the CPU baseline.  Prints ONE JSON line on rank 0.
 """
@@ -205,6 +206,9 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
 
+    # The benchmark has the GPU to itself: queues of 128 M paths per pipeline (118 GB of the 288 GB) instead of the
+    # library's default of 64 M (59 GB), worth about 2 %.  Reported in config.paths_in_flight_per_pipeline.
+    os.environ.setdefault("RTX_WF_CAPACITY", str(1 << 27))
     import torch   # before the package: in a process that holds both, PyTorch's HIP runtime has to be loaded first
     import raytracing_rust_amd as rt
     from raytracing_rust_amd import sharding
@@ -260,11 +264,11 @@ def main():
         scene.render_device(cam, rt.render_opts(cam, sample_begin=b, sample_end=e, seed=seed, pipeline=args.pipeline), accum, stream)
 
     def strong_step(k):
-        # frame k: its rows split between the ranks, then one reduce and the copy to the host
-        first, end = sharding.rank_rows(rank, world_size, args.rows)
+        # frame k: its sample indices split between the ranks, then one reduce and the copy to the host
+        first, end = sharding.rank_samples(rank, world_size, args.rows * rows)
         accum.zero_()
         if end > first:
-            scene.render_device(cam, rt.render_opts(cam, sample_begin=first * rows, sample_end=end * rows,
+            scene.render_device(cam, rt.render_opts(cam, sample_begin=first, sample_end=end,
                                                     seed=rt.scenes.PATH_SEED + 1000 + k, pipeline=args.pipeline), accum, stream)
         return reduce_to_host()
 
@@ -294,11 +298,11 @@ def main():
         return dt, seg, paths, last
 
     results = {}
-    if args.scaling in ("both", "weak") or world_size == 1:
-        results["weak"] = timed(weak_step, reduce_to_host)
-    if world_size > 1 and args.scaling in ("both", "strong"):
+    if args.scaling in ("both", "strong") or world_size == 1:
         results["strong"] = timed(strong_step, None)
-    mode = "weak" if "weak" in results else "strong"
+    if world_size > 1 and args.scaling in ("both", "weak"):
+        results["weak"] = timed(weak_step, reduce_to_host)
+    mode = "strong" if "strong" in results else "weak"
     dt, segments, paths, host = results[mode]
 
     if rank == 0:
@@ -311,21 +315,21 @@ def main():
             "higher_is_better": True, "scaling": mode, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"final scene (final_scene.rs) 800x800, depth 75, step = one render call of {args.rows} of the "
                                    f"70 rows of the 4900-sample stratification = {per_step / 1e6:.1f}M camera paths",
-                       "weak": "every (rank, step) renders that batch with its own path seed; one reduce(sum) of the f64 "
-                               "accumulators and the copy to the host at the end of the timed region",
-                       "strong": "every step is ONE such batch, its rows split between the ranks; reduce(sum) and copy to the "
-                                 "host after every step",
+                       "strong": "every step is ONE such batch (one frame), its sample indices split evenly between the ranks; "
+                                 "reduce(sum) of the f64 accumulators and copy to the host after every step, inside the timed region",
+                       "weak": "every (rank, step) renders that batch with its own path seed; one reduce(sum) and the copy to "
+                               "the host at the end of the timed region",
                        "scene_seed": hex(rt.scenes.SCENE_SEED),
                        "pipelines_per_gpu": int(os.environ.get("RTX_WF_LANES", "4")),
                        "paths_in_flight_per_pipeline": int(os.environ.get("RTX_WF_CAPACITY", str(1 << 27)))},
             "Msegments_per_s": segments / dt / 1e6, "segments_per_path": segments / paths,
         }
-        if "strong" in results and mode != "strong":
-            sdt, sseg, spaths, shost = results["strong"]
-            assert shost is not None and bool(torch.isfinite(shost).all()) and spaths == per_step * args.steps
-            out["strong_scaling"] = {"value": spaths / sdt / 1e6, "unit": "Msamples/s", "ms_per_step": sdt / args.steps * 1e3,
-                                     "steps": args.steps, "Msegments_per_s": sseg / sdt / 1e6,
-                                     "what": "one 800x800 frame per step over all ranks, reduce + copy to the host per frame"}
+        if "weak" in results and mode != "weak":
+            wdt, wseg, wpaths, whost = results["weak"]
+            assert whost is not None and bool(torch.isfinite(whost).all()) and wpaths == per_step * args.steps * world_size
+            out["weak_scaling"] = {"value": wpaths / wdt / 1e6, "unit": "Msamples/s", "ms_per_step": wdt / args.steps * 1e3,
+                                   "steps": args.steps, "Msegments_per_s": wseg / wdt / 1e6,
+                                   "what": "a whole 800x800 frame per rank and step, one reduce + copy to the host at the end"}
     # rank 0 alone: exclusive kernel durations for the roofline block (the other ranks wait at the barrier below)
     if rank == 0:
         if args.roofline_rows > 0:   # 0: a profiler run that wants the timed region alone

@@ -21,7 +21,7 @@ pub fn render(&mut self, world: &dyn Hittable, lights: Option<Arc<dyn Hittable>>
     let seed: u64 = rand::random();                               // the reference's renders are unseeded (random.rs:9-13)
     let st = unsafe { rtx::sys::rtxh_camera_render(s.raw, ctx.raw, &mut desc, w, l, seed, file.as_ptr(),
                                                    std::ptr::null_mut(), std::ptr::null_mut()) };
-    ctx.status(st).expect("render failed");
+    ctx.status_with_session(st, &s).expect("render failed");
     self.image_height = desc.image_height;                        // what initialize() would have left behind
     self.sqrt_spp = desc.sqrt_spp;
 }

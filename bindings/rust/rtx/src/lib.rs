@@ -74,6 +74,23 @@ impl Context {
         let msg = unsafe { CStr::from_ptr(sys::rtx_last_error(self.raw)) }.to_string_lossy().into_owned();
         Err(Error::Device(st, msg))
     }
+    /// Status of a call of the host layer that also used a session (rtxh_camera_render and its progressive form): the
+    /// message of whichever layer failed - the context's, the context-less one of the camera checks, else the
+    /// session's (a failure while flattening leaves its message there and the context's empty).
+    pub fn status_with_session(&self, st: i32, session: &Session) -> Result<(), Error> {
+        if st == sys::RTX_OK {
+            return Ok(());
+        }
+        let text = |p: *const std::os::raw::c_char| unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned();
+        let mut msg = text(unsafe { sys::rtx_last_error(self.raw) });
+        if msg.is_empty() {
+            msg = text(unsafe { sys::rtx_last_error(std::ptr::null()) });
+        }
+        if msg.is_empty() {
+            msg = text(unsafe { sys::rtxh_last_error(session.raw) });
+        }
+        Err(Error::Device(st, msg))
+    }
 }
 
 impl Drop for Context {

@@ -13,11 +13,15 @@
 // golden vectors or fixtures for this path and its toolchain (cargo/rustc) is
 // absent, so no arithmetic result of this restatement can be checked against
 // the reference's.  It is pinned by closed-form known-answer tests
-// (tests/test_oracle_kat.py) and, statistically, by the two output images of
-// deterministic scenes the reference has checked in (images/cornell_box.png,
-// images/output_cornell_smoke.png): renders of this oracle agree with their
-// 30 x 30 block means to 2.4 / 2.6 of 255 on average and to 0.2 of 255 in the
-// global mean (tests/test_reference_images.py).
+// (tests/test_oracle_kat.py) and, statistically, by the five output images of
+// this path's scenes the reference has checked in (tests/test_reference_images.py):
+// images/cornell_box.png and images/output_cornell_smoke.png (deterministic
+// geometry: renders of this oracle agree with their 30 x 30 block means to
+// 2.4 / 2.6 of 255 on average and to 0.2 of 255 in the global mean),
+// images/quick_test.png and images/output_final_scene_800x800_10000spp.png
+// (random geometry per run: 10 x 10 block means within the spread of this
+// build's own scene seeds), images/output_final_scene_800x800_5000spp.png
+// (20 of 255 brighter than the other two of the same scene: layout only).
 // Third-party arithmetic restated from its published semantics:
 //   nalgebra 0.33.2 Vector3<f64>: dot = (x*x' + y*y') + z*z' (no FMA),
 //   norm = sqrt(norm_squared), normalize = component / norm, textbook cross.

@@ -10,8 +10,8 @@
 //   QUAD_AA   idx = first quad, aux = count                    payload count x DAAQuad (10 units)
 //   BOX6      idx = first of the six quads                     payload DBox6 (9 doubles)
 //   ENTER/EXIT idx = transform context, aux = op count         payload ops x {kind, a, b, c}
-//   MEDIUM    idx = medium, aux = first unit of its boundary   payload {neg_inv_density, needs_uv}
-//   MEDIUM_S  idx = medium whose boundary is one static sphere payload {neg_inv_density, needs_uv, DSphere}
+//   MEDIUM    idx = medium, aux = first unit of its boundary   payload {neg_inv_density, flags}
+//   MEDIUM_S  idx = medium whose boundary is one static sphere payload {neg_inv_density, flags, DSphere}
 //   SPHERE    idx = sphere (moving spheres)                    payload {c0[3], dc[3], radius}             (8 units)
 //   QUAD      (general quads): no payload, the walker reads the ABI table
 //   SYNC, NOP, END: no payload; an END closes the world program and every medium boundary program.
@@ -42,6 +42,7 @@ struct CompiledProgram {
   uint32_t n_general_media = 0;    // MEDIUM units emitted (media whose boundary needs a program of its own)
   bool guard_box6 = true;          // a widened box test in front of every BOX6 (tests switch it off to compare)
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
+  bool draw_first_thin_media = true;   // MEDIUM_S of a thin medium draws its free path before intersecting (same)
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
   uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes of this depth (walk_stream_near's shape)
@@ -563,13 +564,14 @@ struct CompiledProgram {
         const DSphere rec = {sp.c0[0], sp.c0[1], sp.c0[2], sp.radius};
         u[0] = (uint64_t)RTX_NODE_MAKE(PROG_NODE_MEDIUM_S, it.idx);
         u[1] = bits(d.media[it.idx].neg_inv_density);
-        u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
+        u[2] = (d.media[it.idx].needs_uv ? PROG_MEDIUM_NEEDS_UV : 0ull) |
+               ((draw_first_thin_media && -d.media[it.idx].neg_inv_density >= 2.0 * sp.radius) ? PROG_MEDIUM_DRAW_FIRST : 0ull);
         memcpy(u + 3, &rec, sizeof(rec));
       } else if (it.kind == RTX_NODE_MEDIUM) {
         ++n_general_media;
         u[0] = (uint64_t)d.nodes[it.node].kind_idx | ((uint64_t)media[it.idx].b_begin << 32);
         u[1] = bits(d.media[it.idx].neg_inv_density);
-        u[2] = (uint64_t)(d.media[it.idx].needs_uv ? 1u : 0u);
+        u[2] = d.media[it.idx].needs_uv ? PROG_MEDIUM_NEEDS_UV : 0ull;
       } else {
         u[0] = (uint64_t)d.nodes[it.node].kind_idx;
         if (it.kind == PROG_NODE_DEFER) defer_pos = p;

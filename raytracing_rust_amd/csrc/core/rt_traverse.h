@@ -91,8 +91,10 @@ struct Scene : rtx_scene_desc {
 #define PROG_QUAD_AA_UNITS 10u   // per quad of a run (DAAQuad)
 #define PROG_BOX6_UNITS 10u      // header + DBox6
 #define PROG_XFORM_OP_UNITS 4u   // per transform op of an ENTER/EXIT record: kind, a, b, c
-#define PROG_MEDIUM_UNITS 3u     // header, neg_inv_density, needs_uv
-#define PROG_MEDIUM_S_UNITS 7u   // header, neg_inv_density, needs_uv, DSphere of the boundary
+#define PROG_MEDIUM_UNITS 3u     // header, neg_inv_density, flags
+#define PROG_MEDIUM_S_UNITS 7u   // header, neg_inv_density, flags, DSphere of the boundary
+#define PROG_MEDIUM_NEEDS_UV 1ull    // flags: the phase texture reads (u, v)
+#define PROG_MEDIUM_DRAW_FIRST 2ull  // flags (MEDIUM_S): mean free path >= the boundary's diameter, draw it before intersecting
 #define PROG_SPHERE_UNITS 8u     // a general (moving) sphere: header, c0[3], dc[3], radius
 #define PROG_NODE_NOP 6u         // filler
 #define PROG_NODE_END 7u         // end of a program (the world's, or a medium boundary's)
@@ -600,25 +602,46 @@ RT_UNROLL
         const bool eval = MEDIA == MEDIA_ALL && running && cls == CL_MEDIUM_EVAL, direct = running && cls == CL_MEDIUM_S;
         if (eval || direct) {
           const uint32_t at = direct ? i : med_at;
+          const double neg_inv_density = ((const double*)prog)[at + 1];
+          const uint64_t mflags = prog[at + 2];   // PROG_MEDIUM_NEEDS_UV | PROG_MEDIUM_DRAW_FIRST
           double t_in = t_entry, t_out = tmax;
-          bool crossed = true;
+          bool crossed = true, drawn = false;
+          double ray_length = 0.0, hit_distance = 0.0;
           if (direct) {
             med = idx; ret_i = i + PROG_MEDIUM_S_UNITS; ret_cur = cur; out_tmax = tmax; out_kind = hit_kind; out_ctx = hit_ctx;
             const DSphere sp = *(const DSphere*)(prog + i + 3);
-            crossed = sphere_s_hit_t(sp, lr.o, lr.d, -RT_INF, RT_INF, t_in) &&
+            if ((mflags & PROG_MEDIUM_DRAW_FIRST) && tmin0 >= 0.0) {
+              // A thin medium (mean free path of at least the boundary's diameter): the free path is drawn FIRST, and a
+              // path longer than any stretch of this ray inside the boundary can be ends the evaluation before the
+              // boundary is intersected.  constant_medium.rs:60-78 then returns false whatever the crossings are: its
+              // distance_inside_boundary = (t2 - t1) * ray_length has 0 < tmin0 <= t1 and t2 <= tmax, so it is at most
+              // tmax * ray_length (rounding is monotone), and at most the sphere's diameter (the two roots differ by
+              // 2 sqrt(disc) / a, a chord; the margin of 1e-9 covers the rounding of the roots for origins within 100
+              // radii).  The draw is addressed by (bounce, medium), so making it early changes no other draw.
+              ray_length = norm(lr.d);
+              hit_distance = neg_inv_density * log(rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med));
+              drawn = true;
+              bool beyond = hit_distance > tmax * ray_length;
+              if (!beyond) {
+                const V3 oc = lr.o - v3(sp.cx, sp.cy, sp.cz);
+                beyond = norm2(oc) <= 1e4 * (sp.r * sp.r) && hit_distance > (2.0 * sp.r) * (1.0 + 1e-9);
+              }
+              crossed = !beyond;
+            }
+            crossed = crossed && sphere_s_hit_t(sp, lr.o, lr.d, -RT_INF, RT_INF, t_in) &&
                       sphere_s_hit_t(sp, lr.o, lr.d, t_in + 0.0001, RT_INF, t_out);
           }
           if (crossed) {
-            const double neg_inv_density = ((const double*)prog)[at + 1];
-            const bool needs_uv = prog[at + 2] != 0;
+            const bool needs_uv = (mflags & PROG_MEDIUM_NEEDS_UV) != 0;
             double t1 = fmax(t_in, tmin0);
             double t2 = fmin(t_out, out_tmax);
             if (!(t1 >= t2)) {
               t1 = fmax(t1, 0.0);
-              double ray_length = norm(lr.d);
+              if (!drawn) {
+                ray_length = norm(lr.d);
+                hit_distance = neg_inv_density * log(rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med));
+              }
               double inside = (t2 - t1) * ray_length;
-              double xi = rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), med);
-              double hit_distance = neg_inv_density * log(xi);
               if (!(hit_distance > inside)) {
                 if (needs_uv && stale_uv) {  // the surface hit this scattering replaces: resolve_hit turns it into (u,v)
                   const uint64_t id = (uint64_t)out_kind | ((uint64_t)out_ctx << 32);
@@ -1246,6 +1269,11 @@ RT_HD RT_NOINLINE WideBest wide_walk_records(const uint64_t* prog, const rtx_qua
     double t;
     if (kind == PROG_NODE_END || kind == PROG_NODE_SYNC) break;
     if (kind == RTX_NODE_BOX) {
+      // A box of the tree inside a leaf slot (a list that holds a box next to primitives): the watch's rules - cull with
+      // the margin, compare a hit with the entry of the innermost box around it - are not kept below it, so outside
+      // the fixed mode the ray is simply handed to the walk in the reference's order.  (The widened guard in front of
+      // a six-face record may be culled with any bound: a face hit within the bound passes it.)
+      if (!b.fixed_mode && idx != PROG_GUARD_IDX) b.suspect = true;
       p = slab_hit((const double*)(prog + p + 1), lr, tmin, b.tmax) ? p + PROG_BOX_UNITS : count;
     } else if (kind == PROG_NODE_SPHERE_S) {
       for (uint32_t k = 0; k < count; ++k) {

@@ -1401,8 +1401,9 @@ static void wf_launch_iteration(rtx_scene* sc, const WfPlan& P, const rtx_camera
 // depends on the one before it, so a single pipeline leaves CUs idle while every launch drains; independent pipelines
 // fill those gaps with each other's kernels.  Measured on the final scene (Msamples/s): 1 pipeline 1928, 2: 1906,
 // 3 x 32 M paths in flight 1960, 4 x 16 M 1731, 4 x 32 M 1933, 4 x 64 M 2058, 5: 1691, 6: 1675.  Default: one pipeline per
-// 4 M camera paths of the call, at most four, each holding at most 128 M paths (29.4 GB; 4 x 64 M 2189, 4 x 128 M 2231,
-// 3 x 96 M 2212) and no more than its share of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
+// 4 M camera paths of the call, at most four, each holding at most 64 M paths (14.7 GB, 59 GB for four; 128 M paths
+// each, RTX_WF_CAPACITY=134217728, takes 118 GB of the 288 GB and gains 2 %: 4 x 64 M 2189, 4 x 128 M 2231, 3 x 96 M 2212)
+// and no more than its share of the call needs.  RTX_WF_LANES and RTX_WF_CAPACITY override both numbers.
 // When device memory does not hold that workspace the capacity is halved until it does (down to 64 K paths).
 static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum_dev, hipStream_t stream) {
   rtx_context* ctx = sc->ctx;
@@ -1415,7 +1416,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const bool head_in_global = sc->dev.head_end != 0 && (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 > kLdsBudget;
   const int want_lanes = lanes_env ? atoi(lanes_env) : head_in_global ? 1 : (int)std::min<unsigned long long>(4ull, (call_paths + (1ull << 22) - 1ull) >> 22);
   const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
-  uint32_t cap = 1u << 27;
+  uint32_t cap = 1u << 26;
   if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 27)) cap = (uint32_t)v; }
   {  // no more than a pipeline's share of the call needs (whole sample indices; at least 64 K)
     const unsigned long long share = per_sample * (unsigned long long)((n_samples + n_lanes - 1) / n_lanes);
@@ -1626,6 +1627,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   if (const char* why = validate_scene(d)) return fail(ctx, RTX_ERR_INVALID, std::string("rtx_scene_create: ") + why);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   CompiledProgram prog;
+  if (const char* e = getenv("RTX_MEDIA_DRAW_FIRST")) prog.draw_first_thin_media = atoi(e) != 0;   // tuning knob: 0 = thin media intersect first too
   prog.compile(*d);
   rtx_scene* sc = new rtx_scene();
   sc->ctx = ctx;

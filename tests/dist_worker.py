@@ -19,12 +19,12 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     g = rt.Graph()
-    w, l, cam = scenes.build("cornell", g, width=24, spp=16, depth=8)
+    w, l, cam = scenes.build("cornell", g, width=24, spp=25 if mode == "whole" else 16, depth=8)
     desc = rt.flatten(g, w, l)
     accum = np.zeros((cam.image_height, cam.image_width, 3))
-    if mode == "whole":          # contiguous rows of one stratification
-        first, end = sharding.rank_rows(rank, world, cam.sqrt_spp)
-        rows = [(r * cam.sqrt_spp, (r + 1) * cam.sqrt_spp, 5) for r in range(first, end)]
+    if mode == "whole":          # one frame: its 25 sample indices split by index (13 and 12: not whole rows of 5)
+        first, end = sharding.rank_samples(rank, world, cam.sqrt_spp ** 2)
+        rows = [(first, end, 5)]
     else:                        # the benchmark's schedule: `steps` rows per rank
         steps = 3
         rows = [sharding.sample_row(rank, k, steps, cam.sqrt_spp, 5) for k in range(steps)]

@@ -23,7 +23,7 @@ static thread_local std::vector<double>* g_ray_log = nullptr;
 
 using namespace rt;
 
-static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true;  // compile options under test
+static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true, g_draw_first = true;  // compile options under test
 static int g_near_walks = 0, g_top_walks = 0, g_wide_walks = 0;
 static double g_near_margin = 0.0;
 static int g_head_table = 2;  // head section in global memory: 2 = the folded table when the program has one, 1 = first levels in heap order, 0 = neither
@@ -34,7 +34,7 @@ extern "C" {
 int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                   uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -87,7 +87,7 @@ static int g_redos = 0;
 int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                          uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   Scene S = prog.host_view(*desc);
   if (g_near_margin > 0.0) S.near_margin = g_near_margin;
   if (!S.head_end && !S.tail_begin) return -1;
@@ -226,13 +226,14 @@ int sim_top_walks(void) { return g_top_walks; }        // head sections walked w
 int sim_order_redos(void) { return g_redos; }          // rays of the last staged walk that went through the fixed order again   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
+void sim_set_draw_first(int on) { g_draw_first = on != 0; }   // thin sphere-bounded media draw their free path first
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }
 
 // counters: paths, segments, pdf_probes
 int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
                uint64_t* counters, int nthreads) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   if (nthreads < 1) nthreads = 1;
@@ -270,7 +271,7 @@ int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx
 // bytes, len receives the per-ray lengths.
 void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, uint32_t cap, uint8_t* seq, uint32_t* len) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene S = prog.host_view(*desc);
   for (size_t i = 0; i < n; ++i) {
     const double* r = rays + 7 * i;
@@ -289,7 +290,7 @@ void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, u
 // Histogram of unit kinds of the compiled program (16 counters) + total units in counts[16].
 void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   for (int k = 0; k < 17; ++k) counts[k] = 0;
   for (size_t i = 0; i < prog.units.size();) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)prog.units[i]);
@@ -314,7 +315,7 @@ void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x3
 void sim_philox10(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32_r<10>(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* uvp, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -324,14 +325,14 @@ void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* u
 }
 void sim_lights_pdf(const rtx_scene_desc* desc, const double* origin, const double* dirs, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); }
 }
 void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_t seed, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -348,7 +349,7 @@ void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_
 struct SimScene { CompiledProgram prog; Scene view; };
 void* sim_scene_new(const rtx_scene_desc* desc) {      // the compiled program of a description, kept for many probe calls
   SimScene* h = new SimScene();
-  h->prog.fuse_sphere_media = g_fuse_sphere_media; h->prog.defer_last_section = g_defer_last_section; h->prog.guard_box6 = g_guard_box6;
+  h->prog.fuse_sphere_media = g_fuse_sphere_media; h->prog.draw_first_thin_media = g_draw_first; h->prog.defer_last_section = g_defer_last_section; h->prog.guard_box6 = g_guard_box6;
   h->prog.compile(*desc);
   h->view = h->prog.host_view(*desc);
   return h;

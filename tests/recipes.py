@@ -214,7 +214,7 @@ def ties_on_box_boundaries(g):
 def material_probe(g):
     """Every material under a sphere light and a quad light, with a medium: metal with and without fuzz, glass (hit from
     outside and, by rays that start inside it, from inside at angles beyond the critical one), Lambertian, a
-    box-bounded and a sphere-bounded medium, a moving sphere."""
+    box-bounded medium, a dense and a thin sphere-bounded medium, a moving sphere."""
     red, white = g.lambertian_color(0.65, 0.05, 0.05), g.lambertian_color(0.73, 0.73, 0.73)
     light = g.diffuse_light_color(9, 8, 7)
     floor = g.quad((-60, 0, -60), (120, 0, 0), (0, 0, 120), white)
@@ -225,9 +225,12 @@ def material_probe(g):
     mover = g.sphere_moving((0, 30, -20), (0, 36, -20), 5.0, white)
     smoke = g.medium(g.translate(g.rotate_y(g.box((0, 0, 0), (16, 16, 16), white), 25.0), (-20, 0, 25)), 0.08, g.solid(0.9, 0.9, 0.9))
     haze = g.medium(g.sphere((20, 8, 28), 8.0, white), 0.15, g.solid(0.2, 0.4, 0.9))
+    # thin and large (mean free path 1000 against a diameter of 400): the device core draws its free path before it
+    # intersects the boundary and mostly skips the intersection
+    mist = g.medium(g.sphere((0, 20, 0), 200.0, white), 0.001, g.solid(0.8, 0.8, 0.8))
     quad_light = g.quad((-15, 70, -15), (30, 0, 0), (0, 0, 30), light)
     sphere_light = g.sphere((45, 45, 20), 6.0, light)
-    world = g.list([floor, back, metal, fuzzy, glass, mover, smoke, haze, quad_light, sphere_light])
+    world = g.list([floor, back, metal, fuzzy, glass, mover, smoke, haze, mist, quad_light, sphere_light])
     lights = g.list([g.quad((-15, 70, -15), (30, 0, 0), (0, 0, 30), g.none()), g.sphere((45, 45, 20), 6.0, g.none())])
     cam = dict(aspect_ratio=1.0, image_width=64, samples_per_pixel=16, max_depth=12, background=(0.02, 0.03, 0.05),
                vfov=55.0, lookfrom=(0.0, 35.0, 110.0), lookat=(0.0, 15.0, 0.0))

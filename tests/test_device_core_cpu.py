@@ -254,3 +254,26 @@ def test_box6_guards_never_change_a_result(name, width):
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     H.assert_aov_equal(ha, hb, name)
     assert np.isfinite(ha["t"][-len(graze):]).sum() > len(graze) // 2
+
+
+@pytest.mark.parametrize("name,width", [("final", 40)])
+def test_thin_media_drawn_first_are_bit_identical(name, width):
+    """A sphere-bounded medium whose mean free path is at least its boundary's diameter (the final scene's fog:
+    radius 5000, density 1e-4, final_scene.rs:120-129) draws its free path before it intersects the boundary and leaves
+    when the path is longer than the ray can be inside (constant_medium.rs:60-78 returns false then, whatever the
+    crossings).  The render must not change by a bit against the form that intersects first."""
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=width, spp=16, depth=12)
+    desc = rt.flatten(g, w, l)
+    opts = rt.render_opts(cam, sample_begin=0, sample_end=16, seed=6)
+    lib = H.hostsim_lib()
+    try:
+        lib.sim_set_draw_first(0)
+        a, ca = H.hostsim_render(desc, cam, opts)
+        lib.sim_set_draw_first(1)
+        b, cb = H.hostsim_render(desc, cam, opts)
+    finally:
+        lib.sim_set_draw_first(1)
+    assert ca == cb
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert a.sum() > 0

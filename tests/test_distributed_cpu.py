@@ -23,9 +23,9 @@ def launch(tmp_path, mode, port):
     return np.load(out)
 
 
-def single(rows):
+def single(rows, spp=16):
     g = rt.Graph()
-    w, l, cam = scenes.build("cornell", g, width=24, spp=16, depth=8)
+    w, l, cam = scenes.build("cornell", g, width=24, spp=spp, depth=8)
     desc = rt.flatten(g, w, l)
     accum = np.zeros((cam.image_height, cam.image_width, 3))
     for (b, e, seed) in rows:
@@ -44,6 +44,16 @@ def test_rank_rows_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_rank_samples_differ_by_at_most_one():
+    """One frame's sample indices over the ranks: contiguous, complete, shares within one index of each other."""
+    for world in (1, 2, 3, 5, 8):
+        spans = [sharding.rank_samples(r, world, 4900) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 4900 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [e - b for b, e in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [e - b for b, e in (sharding.rank_samples(r, 8, 4900) for r in range(8))] == [613] * 4 + [612] * 4
+
+
 def test_sample_rows_are_disjoint_over_ranks_and_steps():
     seen = set()
     for rank in range(8):
@@ -56,8 +66,9 @@ def test_sample_rows_are_disjoint_over_ranks_and_steps():
 
 def test_two_ranks_whole_image_equals_one_process(tmp_path):
     two = launch(tmp_path, "whole", 29511)
-    one, cam = single([(r * 4, (r + 1) * 4, 5) for r in range(4)])
+    one, cam = single([(0, 25, 5)], spp=25)
     assert np.allclose(two, one, rtol=1e-13, atol=0)      # same paths, summed in another order
+    assert one.sum() > 0
 
 
 def test_two_ranks_bench_schedule_equals_one_process(tmp_path):

@@ -125,7 +125,7 @@ def _probe_both(**cam_over):
 
 def test_materials_replayed_on_probe_scene():
     go, wo, lo, dev, cam, desc = _probe_both()
-    assert desc.n_media == 2
+    assert desc.n_media == 3
     rng = np.random.default_rng(5)
     n = 0
     for _ in range(1500):                                   # camera paths
@@ -153,8 +153,8 @@ def test_materials_replayed_on_probe_scene():
         d = rng.normal(size=3)
         ray = np.array([*o, *d, 0.3])
         a, _ = R.compare_path(go, wo, lo, dev, cam, rng, desc.n_media, ray=ray)
-        first_level = a["tags"][((a["tags"] >> 8) & 0xFFF) == 0]
-        no_draw += len(first_level) == 0 and len(a["rays"]) > 1
+        first_level = a["tags"][(((a["tags"] >> 8) & 0xFFF) == 0) & ((a["tags"] & 0xFF) == R.TAG_SHADE)]
+        no_draw += len(first_level) == 0 and len(a["rays"]) > 1 and np.linalg.norm(a["rays"][1, :3] - np.array([0.0, 12.0, 10.0])) < 12.001
     assert no_draw > 60
 
 
