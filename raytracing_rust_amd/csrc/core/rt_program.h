@@ -56,9 +56,93 @@ struct CompiledProgram {
   uint32_t head_wide_begin = 0, head_wide_nodes = 0, head_wide_depth = 0; // Scene::head_wide_*: the head section's box tree, two levels per record
   bool head_wide = true;                             // build that table (tests switch it off to compare)
 
+  // The light table (Scene::light_nodes): per group of 64 consecutive light leaves a median-split tree over their
+  // boxes.  A leaf's box bounds its primitive in WORLD space - a quad's four corners, a static sphere's centre +- radius
+  // (Sphere::pdf_value probes the sphere of time 0, sphere.rs:135), carried out of the leaf's transform context corner
+  // by corner - widened by 1e-6 of (1 + its largest coordinate): the rounding of the reference's hit tests and of the
+  // slab test is many orders of magnitude below that for probe origins within light_far, so a ray that misses the
+  // widened box cannot be accepted by Quad::hit / Sphere::hit.  Lights of kind NONE have no box (their pdf is 0).
+  std::vector<LightNode> light_nodes;
+  std::vector<uint32_t> light_group_begin;
+  double light_far = 0.0;
+  bool light_table = true;         // build it (tests switch it off to compare)
+  void build_light_table(const rtx_scene_desc& d) {
+    light_nodes.clear(); light_group_begin.clear(); light_far = 0.0;
+    if (!light_table || d.n_lights < LIGHT_TABLE_MIN) return;
+    struct Leaf { double lo[3], hi[3]; uint32_t light; };
+    double extent = 0.0;
+    auto leaf_of = [&](uint32_t i, Leaf& lf) -> bool {
+      const rtx_light& L = d.lights[i];
+      if (L.kind != RTX_NODE_QUAD && L.kind != RTX_NODE_SPHERE) return false;
+      double c[8][3];
+      int nc = 0;
+      if (L.kind == RTX_NODE_QUAD) {
+        const rtx_quad& q = d.quads[L.idx];
+        for (int k = 0; k < 4; ++k, ++nc)
+          for (int a = 0; a < 3; ++a) c[nc][a] = q.q[a] + ((k & 1) ? q.u[a] : 0.0) + ((k & 2) ? q.v[a] : 0.0);
+      } else {
+        const rtx_sphere& sp = d.spheres[L.idx];
+        const double r = fabs(sp.radius);
+        for (int k = 0; k < 8; ++k, ++nc)
+          for (int a = 0; a < 3; ++a) c[nc][a] = sp.c0[a] + (((k >> a) & 1) ? r : -r);
+      }
+      for (int a = 0; a < 3; ++a) { lf.lo[a] = INFINITY; lf.hi[a] = -INFINITY; }
+      for (int k = 0; k < nc; ++k) {
+        double p[3] = {c[k][0], c[k][1], c[k][2]};
+        const rtx_xform x = d.xforms[L.ctx];            // context -> world: innermost first (ctx_to_world)
+        for (uint32_t s = x.n_ops; s > 0; --s) {
+          const rtx_xform_op op = d.xform_ops[x.first_op + s - 1];
+          if (op.kind == RTX_XF_TRANSLATE) { p[0] += op.a; p[1] += op.b; p[2] += op.c; }
+          else { const double px = op.b * p[0] + op.a * p[2], pz = -op.a * p[0] + op.b * p[2]; p[0] = px; p[2] = pz; }
+        }
+        for (int a = 0; a < 3; ++a) { lf.lo[a] = std::min(lf.lo[a], p[a]); lf.hi[a] = std::max(lf.hi[a], p[a]); }
+      }
+      for (int a = 0; a < 3; ++a) {
+        if (!(fabs(lf.lo[a]) < 1e300) || !(fabs(lf.hi[a]) < 1e300)) return false;
+        const double pad = 1e-6 * (1.0 + std::max(fabs(lf.lo[a]), fabs(lf.hi[a])));
+        lf.lo[a] -= pad; lf.hi[a] += pad;
+        extent = std::max(extent, std::max(fabs(lf.lo[a]), fabs(lf.hi[a])));
+      }
+      lf.light = i;
+      return true;
+    };
+    std::function<void(std::vector<Leaf>&, size_t, size_t)> emit = [&](std::vector<Leaf>& v, size_t b, size_t e) {
+      LightNode nd;
+      for (int a = 0; a < 3; ++a) { nd.lo[a] = INFINITY; nd.hi[a] = -INFINITY; }
+      for (size_t k = b; k < e; ++k)
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = std::min(nd.lo[a], v[k].lo[a]); nd.hi[a] = std::max(nd.hi[a], v[k].hi[a]); }
+      const size_t at = light_nodes.size();
+      nd.skip = 0; nd.light = e - b == 1 ? v[b].light : LIGHT_NODE_INNER;
+      light_nodes.push_back(nd);
+      if (e - b > 1) {
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (nd.hi[a] - nd.lo[a] > nd.hi[axis] - nd.lo[axis]) axis = a;
+        std::sort(v.begin() + (long)b, v.begin() + (long)e, [axis](const Leaf& x, const Leaf& y) { return x.lo[axis] + x.hi[axis] < y.lo[axis] + y.hi[axis]; });
+        const size_t mid = b + (e - b) / 2;
+        emit(v, b, mid); emit(v, mid, e);
+      }
+      light_nodes[at].skip = (uint32_t)light_nodes.size();
+    };
+    bool whole = true;   // a light whose box cannot be made (a non-finite record) must still be evaluated: no table then
+    for (uint32_t g0 = 0; g0 < d.n_lights && whole; g0 += 64u) {
+      light_group_begin.push_back((uint32_t)light_nodes.size());
+      std::vector<Leaf> leaves;
+      for (uint32_t i = g0; i < std::min(d.n_lights, g0 + 64u); ++i) {
+        Leaf lf;
+        if (leaf_of(i, lf)) leaves.push_back(lf);
+        else if (d.lights[i].kind != RTX_NODE_NONE) whole = false;
+      }
+      if (!leaves.empty()) emit(leaves, 0, leaves.size());
+    }
+    light_group_begin.push_back((uint32_t)light_nodes.size());
+    if (!whole || light_nodes.empty()) { light_nodes.clear(); light_group_begin.clear(); return; }
+    light_far = 1e6 * (1.0 + extent);
+  }
+
   // `d` must already be validated (index ranges, forward skip links that stay inside their program, no medium inside
   // a medium boundary).
   void compile(const rtx_scene_desc& d) {
+    build_light_table(d);
     units.clear();
     n_box6 = 0;
     build_compact(d);
@@ -122,6 +206,9 @@ struct CompiledProgram {
     S.head_end = head_end; S.tail_near_depth = tail_near_depth; S.head_near_depth = head_near_depth; S.tail_near_quads = tail_near_quads; S._pad_near = 0; S.fresh_in_main = 0; S.light_quads = nullptr; S.light_spheres = nullptr; S.near_margin = RT_NEAR_MARGIN;
     S.head_top_begin = head_top_begin; S.head_top_nodes = head_top_nodes; S.head_top_units = head_top_units;
     S.head_wide_begin = head_wide_begin; S.head_wide_nodes = head_wide_nodes; S.head_wide_depth = head_wide_depth; S._pad_wide = 0; S.head_wide_far = head_wide_far;
+    S.light_nodes = light_nodes.data(); S.n_light_nodes = (uint32_t)light_nodes.size();
+    S.n_light_groups = light_group_begin.empty() ? 0u : (uint32_t)light_group_begin.size() - 1u;
+    S.light_group_begin = light_group_begin.data(); S.light_far = light_far;
     return S;
   }
 

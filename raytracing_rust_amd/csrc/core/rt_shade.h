@@ -162,19 +162,49 @@ RT_HD V3 quad_random(const rtx_quad& q, const V3& origin, PathRng& rng) {
 }
 
 // HittablePDF::value over the flattened light leaves (hittable_pdf.rs:25-27 -> hittable_list.rs:78-88 etc.)
+RT_HD double light_pdf_term(const Scene& S, uint32_t i, const V3& origin, const V3& dir, uint32_t& probes) {
+  const rtx_light L = S.lights[i];
+  double pv = 0.0;
+  if (L.kind != RTX_NODE_NONE) {
+    V3 o = origin, d = dir;
+    if (L.ctx != 0) { o = ctx_point_to_local(S, L.ctx, o); d = ctx_dir_to_local(S, L.ctx, d); }
+    if (L.kind == RTX_NODE_QUAD) pv = quad_pdf_value(S.light_quads ? S.light_quads[i] : S.quads[L.idx], o, d);
+    else pv = sphere_pdf_value(S.light_spheres ? S.light_spheres[i] : S.spheres[L.idx], o, d);
+    ++probes;
+  }
+  return L.weight * pv;
+}
 RT_HD double lights_pdf_value(const Scene& S, const V3& origin, const V3& dir, uint32_t& probes) {
   double sum = 0.0;
-  for (uint32_t i = 0; i < S.n_lights; ++i) {
-    const rtx_light L = S.lights[i];
-    double pv = 0.0;
-    if (L.kind != RTX_NODE_NONE) {
-      V3 o = origin, d = dir;
-      if (L.ctx != 0) { o = ctx_point_to_local(S, L.ctx, o); d = ctx_dir_to_local(S, L.ctx, d); }
-      if (L.kind == RTX_NODE_QUAD) pv = quad_pdf_value(S.light_quads ? S.light_quads[i] : S.quads[L.idx], o, d);
-      else pv = sphere_pdf_value(S.light_spheres ? S.light_spheres[i] : S.spheres[L.idx], o, d);
-      ++probes;
+  const bool table = S.n_light_nodes != 0 && fabs(origin.x) <= S.light_far && fabs(origin.y) <= S.light_far && fabs(origin.z) <= S.light_far;
+  if (!table) {
+    for (uint32_t i = 0; i < S.n_lights; ++i) sum += light_pdf_term(S, i, origin, dir, probes);
+    return sum;
+  }
+  // With many lights: only those whose widened box the probe ray passes over [0.001, inf) are evaluated - every other
+  // light's pdf_value is exactly 0 (its hit test fails), and adding w * 0 leaves the sum as it is - in the list's order
+  // (hittable_list.rs:84-86), group of 64 by group of 64, so the sum is the reference's to the last bit.
+  const LRay lr = lray_from_ops(nullptr, 0, origin, dir);
+  for (uint32_t g = 0; g < S.n_light_groups; ++g) {
+    unsigned long long mask = 0ull;
+    uint32_t k = S.light_group_begin[g];
+    const uint32_t end = S.light_group_begin[g + 1u];
+    while (k < end) {
+      const LightNode* nd = S.light_nodes + k;
+      const double b[6] = {nd->lo[0], nd->lo[1], nd->lo[2], nd->hi[0], nd->hi[1], nd->hi[2]};
+      const uint32_t skip = nd->skip, light = nd->light;
+      if (slab_hit(b, lr, 0.001, RT_INF)) {
+        if (light != LIGHT_NODE_INNER) mask |= 1ull << (light - 64u * g);
+        k += 1u;
+      } else {
+        k = skip;
+      }
     }
-    sum += L.weight * pv;
+    while (mask) {
+      const uint32_t bit = (uint32_t)__builtin_ctzll(mask);
+      mask &= mask - 1ull;
+      sum += light_pdf_term(S, 64u * g + bit, origin, dir, probes);
+    }
   }
   return sum;
 }

@@ -70,6 +70,14 @@ struct Scene : rtx_scene_desc {
   const rtx_quad* light_quads;
   const rtx_sphere* light_spheres;
   double near_margin;   // relative margin of the nearer-child-first walk's order-dependence watch (RT_NEAR_MARGIN by default)
+  // Boxes over the light leaves, for HittablePDF::value (lights_pdf_value): a probe ray that misses a light's widened
+  // box gets exactly 0 from that light (its Sphere/Quad::pdf_value begins with a hit test, sphere.rs:126, quad.rs:103),
+  // so only the lights whose boxes it passes are evaluated.  Groups of 64 consecutive lights, each a small tree of
+  // LightNode in depth-first order; n_light_nodes = 0: no table (few lights), every light is evaluated.
+  const struct LightNode* light_nodes;
+  uint32_t n_light_nodes, n_light_groups;
+  const uint32_t* light_group_begin;   // n_light_groups + 1 node positions
+  double light_far;     // the table serves probe origins whose coordinates are within this
   // Top of the head section's box tree, for a walk of a program that stays in global memory: copies of the box records
   // of its first levels in heap order (root 0, children of h at 2h+1 and 2h+2), 7 units each, at unit head_top_begin of
   // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none;
@@ -81,6 +89,13 @@ struct Scene : rtx_scene_desc {
   uint32_t head_wide_begin, head_wide_nodes, head_wide_depth, _pad_wide;   // depth: records on the longest way down
   double head_wide_far;   // the table serves rays whose origin coordinates are within this (see build_head_wide)
 };
+struct LightNode {     // a box of the light table: world space, widened (see CompiledProgram::build_light_table)
+  double lo[3], hi[3];
+  uint32_t skip;       // node to go on with when the ray misses this box (all nodes of a group lie between its bounds)
+  uint32_t light;      // leaf: index of the light (rtx_scene_desc::lights); inner node: LIGHT_NODE_INNER
+};
+#define LIGHT_NODE_INNER 0xFFFFFFFFu
+#define LIGHT_TABLE_MIN 8u                 // scenes with fewer lights evaluate them all: a box test costs what a light does
 #define PROG_WIDE_PAD 2e-6                 // pad of the table's bounds, relative to the section's largest coordinate
 #define PROG_WIDE_FAR 1e9                  // origins this many times farther out than that are walked over the program
 #define PROG_WIDE_UNITS 16u                // four boxes (6 floats each, rounded outward), four slot descriptors

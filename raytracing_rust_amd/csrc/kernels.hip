@@ -107,6 +107,7 @@ struct WfCounters {
   alignas(128) uint32_t work_tail;  // ... in the deferred-section launch
   alignas(128) uint32_t work_shade; // ... in the shading launch
   alignas(128) uint32_t work_head;  // ... in the head-section launch
+  alignas(128) uint32_t work_finish; // survivors the finishing kernel's workgroups have taken beyond their first ones
   // Device-side timing of the world-program traversal launches (wall_clock64 ticks): first block in, last block out
   // of the current launch; sum and number of the launches completed so far.  HIP events cannot time a kernel while
   // other pipelines share the GPU: they would include the wait for a free CU.
@@ -126,7 +127,7 @@ struct WfFrame {       // what a path index means: (sample offset, pixel rank); 
 
 __global__ void k_wf_begin(WfCounters* c, unsigned long long total) {
   c->n_in = 0; c->n_out = 0; c->gen_count = 0; c->gen_slot = 0; c->gen_sample = 0; c->gen_rem = 0;
-  c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
+  c->finished = 0; c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0; c->work_finish = 0;
   c->next_path = 0; c->total_paths = total;
   c->k1_start = ~0ull; c->k1_end = 0ull; c->k1_sum = 0ull; c->k1_count = 0ull;
   c->sh_start = ~0ull; c->sh_end = 0ull; c->sh_sum = 0ull; c->sh_count = 0ull;
@@ -147,7 +148,7 @@ __global__ void k_wf_prepare(WfCounters* c, uint32_t cap, uint32_t per_sample, u
   c->next_path += g;
   c->n_in = survivors + g;
   c->n_out = 0;
-  c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0;
+  c->n_defer = 0; c->work_main = 0; c->work_tail = 0; c->work_shade = 0; c->work_head = 0; c->work_finish = 0;
   if (g) atomicAdd(&stats[0], (unsigned long long)g);  // two pipelines may be preparing at the same time
   if (count_segments && survivors + g) atomicAdd(&stats[1], (unsigned long long)(survivors + g));  // no world-program launch will
 }
@@ -775,26 +776,60 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
   if (blockIdx.x == 0 && threadIdx.x == 0) wf_flush_timing(c);
   if (n == 0 || n > threshold || c->next_path != c->total_paths) return;
   if (blockIdx.x * blockDim.x >= n) return;
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   const V3 bg = v3(cam.background);
-  bool alive = idx < n;
-  const uint32_t ld = alive ? idx : 0;
-  const double* f = qin.f + ld;
+  const uint32_t lane = threadIdx.x & 63u;
+  // The workgroups are persistent: a thread starts with the survivor of its own number and, whenever its path has
+  // ended, takes the next one nobody has taken yet (one atomic per wave and bounce for the lanes that are free), so a
+  // workgroup is not held by its longest path while its other lanes idle.  Paths do not depend on each other and
+  // their random numbers are addressed by their own coordinates: who traces which changes nothing.
+  const uint32_t first_free = gridDim.x * blockDim.x;   // survivors below this number have an owner from the start
+  bool more = first_free < n;                            // (uniform over a wave) survivors may be left to take
   Ray ray;
-  ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
-  ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
-  ray.tm = f[6 * (size_t)cap];
+  ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.tm = 0.0;
   PathState ps;
-  ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
-  ps.L = v3(0.0, 0.0, 0.0);
-  const uint32_t* u = qin.u + ld;
-  const uint32_t pixel = u[0], sample = u[(size_t)cap], db = u[2 * (size_t)cap];
-  ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
-  ps.rng = rng_make(seed, pixel, sample);
-  alive = alive && ps.depth > 0;   // a dead entry of the shading kernel
+  ps.T = v3(0, 0, 0); ps.L = v3(0, 0, 0); ps.depth = 0; ps.bounce = 0; ps.rng = rng_make(seed, 0, 0);
+  uint32_t pixel = 0;
+  bool alive = false;
+  auto load_path = [&](uint32_t idx) {
+    const double* f = qin.f + idx;
+    ray.o = v3(f[0 * (size_t)cap], f[1 * (size_t)cap], f[2 * (size_t)cap]);
+    ray.d = v3(f[3 * (size_t)cap], f[4 * (size_t)cap], f[5 * (size_t)cap]);
+    ray.tm = f[6 * (size_t)cap];
+    ps.T = v3(f[7 * (size_t)cap], f[8 * (size_t)cap], f[9 * (size_t)cap]);
+    ps.L = v3(0.0, 0.0, 0.0);
+    const uint32_t* u = qin.u + idx;
+    const uint32_t sample = u[(size_t)cap], db = u[2 * (size_t)cap];
+    pixel = u[0];
+    ps.depth = (int)(db >> 16); ps.bounce = db & 0xFFFFu;
+    ps.rng = rng_make(seed, pixel, sample);
+    alive = ps.depth > 0;   // depth 0: a dead entry of the shading kernel
+  };
+  {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) load_path(idx);
+  }
   uint32_t segs = 0, probes = 0;
   const uint32_t main_units = S.tail_begin ? S.tail_begin : S.n_units, tail_units = S.tail_begin ? S.n_units - S.tail_begin : 0u;   // both even
-  while (__syncthreads_or(alive ? 1 : 0)) {   // (the barrier also keeps the staged image until every wave is through with it)
+  for (;;) {
+    if (more) {   // lanes without a path take the next survivors
+      const unsigned long long want = __ballot(!alive);
+      if (want) {
+        const uint32_t cnt = (uint32_t)__popcll(want);
+        uint32_t base = 0;
+        if (lane == (uint32_t)(__ffsll((long long)want) - 1)) base = atomicAdd(&c->work_finish, cnt);
+        base = __shfl(base, __ffsll((long long)want) - 1) + first_free;
+        const uint32_t mine = base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+        if (!alive && mine < n) load_path(mine);
+        if (base + cnt >= n) more = false;
+      }
+    }
+    // (the barriers also keep the staged image until every wave is through with it)
+    const int any_alive = __syncthreads_or(alive ? 1 : 0);
+    const int any_more = __syncthreads_or(more ? 1 : 0);
+    if (!any_alive) {
+      if (any_more) continue;   // everything taken so far was a dead entry: take again
+      break;
+    }
     {
       const uint4* src = (const uint4*)S.prog;
       uint4* dst = (uint4*)lds_prog;
@@ -1210,7 +1245,7 @@ static rtx_status wf_ensure(rtx_context* ctx, int lane, uint32_t want, bool* oom
 // walked from global memory is finished late: its finishing kernel walks the program in the reference's order, a
 // bounce of which costs more than an iteration over a short queue (stress scene: 65536: 171, 4096: 176 Msamples/s).
 static unsigned finish_threshold(bool head_in_global) {
-  unsigned v = head_in_global ? 4096u : 64u * 1024u;
+  unsigned v = head_in_global ? 4096u : 128u * 1024u;   // (from LDS, persistent workgroups: `quick` 65536: 1110, 131072 and 262144: 1165, 524288: 1040 Msamples/s)
   if (const char* e = getenv("RTX_WF_FINISH")) { long x = atol(e); if (x >= 256 && x <= (1l << 22)) v = ((unsigned)x + 511u) & ~511u; }
   return v;
 }
@@ -1462,6 +1497,10 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   int chunk = 4;   // (8: quick 1081, 4: 1097-1114 Msamples/s; the large render does not care)
   if (const char* e = getenv("RTX_WF_CHUNK")) { const int v = atoi(e); if (v >= 2 && v <= 64) chunk = v & ~1; }   // even: the queues swap roles every iteration
   const bool timed_sections = n_lanes == 1;
+  // persistent workgroups of the finishing kernel (one per CU for its LDS): the pipelines of a call reach that stage at
+  // about the same time and share the CUs
+  unsigned finish_blocks = std::max(16u, (unsigned)ctx->n_cus / (unsigned)n_lanes);
+  if (const char* e = getenv("RTX_WF_FINISH_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) finish_blocks = (unsigned)v; }
   for (bool all_done = false; !all_done;) {
     all_done = true;
     for (int it = 0; it < chunk; ++it)
@@ -1477,7 +1516,7 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       rtx_context::WfLane& L = *r.L;
       hipStream_t s = r.s;
       if (P.k_finish_lds)
-        hipLaunchKernelGGL(P.k_finish_lds, dim3((P.finish_at + RT_FINISH_THREADS - 1) / RT_FINISH_THREADS), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
+        hipLaunchKernelGGL(P.k_finish_lds, dim3(std::min<unsigned>((P.finish_at + RT_FINISH_THREADS - 1) / RT_FINISH_THREADS, finish_blocks)), dim3(RT_FINISH_THREADS), P.finish_lds_bytes, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       else
         hipLaunchKernelGGL(k_wf_finish, dim3(P.finish_at / 256), dim3(256), 0, s, sc->dev, *cam, cap, seed, use_lights, (uint32_t)P.finish_at, L.c, L.q[r.cur], accum_dev, ctx->d_counters);
       HIP_TRY(ctx, hipGetLastError());
@@ -1488,16 +1527,28 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
       Run& r = runs[l];
       if (r.done) continue;
       rtx_context::WfLane& L = *r.L;
-      if (r.k > 0) {
-        HIP_TRY(ctx, hipEventSynchronize(L.ev[(r.k - 1) & 1]));
-        const WfCounters& c = L.host[(r.k - 1) & 1];
-        r.done = (c.n_out == 0 || c.finished != 0) && c.next_path == c.total_paths;   // finished: k_wf_finish ran the survivors to their end
+      // counters of chunk `kk`: is the pipeline through?  (finished: a finishing kernel ran the survivors to their end)
+      auto look = [&](int kk) -> hipError_t {
+        const hipError_t e = hipEventSynchronize(L.ev[kk & 1]);
+        if (e != hipSuccess) return e;
+        const WfCounters& c = L.host[kk & 1];
+        r.done = (c.n_out == 0 || c.finished != 0) && c.next_path == c.total_paths;
         if (r.done) {  // the traversal launches of this pipeline, timed on the device
           ctx->traverse_ms += (double)c.k1_sum / ctx->wall_clock_khz;
           ctx->traverse_launches += c.k1_count;
           ctx->shade_ms += (double)c.sh_sum / ctx->wall_clock_khz;
           ctx->shade_launches += c.sh_count;
         }
+        return hipSuccess;
+      };
+      if (r.k > 0) {
+        HIP_TRY(ctx, look(r.k - 1));
+        // The host runs one chunk ahead of the counters it has seen.  When those say that no camera path is left to
+        // start and the survivors are few enough for the chunk just enqueued to end with the finishing kernel (a queue
+        // shrinks to a tenth over four bounces), the next chunk would be nothing but empty launches - 64 of them at the
+        // end of a small call, most of a millisecond: wait for the counters of the chunk just enqueued instead.
+        const WfCounters& c = L.host[(r.k - 1) & 1];
+        if (!r.done && c.next_path == c.total_paths && (unsigned long long)c.n_out <= 8ull * P.finish_at) HIP_TRY(ctx, look(r.k));
       }
       if (r.closed && !r.done) { r.closed = false; r.limit = 0x7FFFFFFF; }   // (not expected: go on chunk by chunk)
       else if (r.iters >= r.limit) r.closed = true;                          // only the counters of this chunk are still to come
@@ -1628,6 +1679,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   CompiledProgram prog;
   if (const char* e = getenv("RTX_MEDIA_DRAW_FIRST")) prog.draw_first_thin_media = atoi(e) != 0;   // tuning knob: 0 = thin media intersect first too
+  if (const char* e = getenv("RTX_LIGHT_TABLE")) prog.light_table = atoi(e) != 0;                  // tuning knob: 0 = every light is evaluated
   prog.compile(*d);
   rtx_scene* sc = new rtx_scene();
   sc->ctx = ctx;
@@ -1648,7 +1700,13 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
     }
     sc->nothing_behind_head = nothing;
   }
+  sc->dev.light_nodes = nullptr; sc->dev.light_group_begin = nullptr;
+  sc->dev.n_light_nodes = (uint32_t)prog.light_nodes.size();
+  sc->dev.n_light_groups = prog.light_group_begin.empty() ? 0u : (uint32_t)prog.light_group_begin.size() - 1u;
+  sc->dev.light_far = prog.light_far;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
+  if (st == RTX_OK) st = upload(sc, prog.light_nodes.data(), prog.light_nodes.size(), &sc->dev.light_nodes);
+  if (st == RTX_OK) st = upload(sc, prog.light_group_begin.data(), prog.light_group_begin.size(), &sc->dev.light_group_begin);
   if (st == RTX_OK) st = upload(sc, prog.media.data(), prog.media.size(), &sc->dev.media);
 #define UP(field, count) if (st == RTX_OK) st = upload(sc, d->field, (size_t)(count), &sc->dev.field)
   UP(boxes, d->n_boxes); UP(spheres, d->n_spheres); UP(quads, d->n_quads);

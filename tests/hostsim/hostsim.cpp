@@ -23,7 +23,8 @@ static thread_local std::vector<double>* g_ray_log = nullptr;
 
 using namespace rt;
 
-static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true, g_draw_first = true;  // compile options under test
+static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true, g_draw_first = true, g_light_table = true;  // compile options under test
+static uint64_t g_last_probes = 0;
 static int g_near_walks = 0, g_top_walks = 0, g_wide_walks = 0;
 static double g_near_margin = 0.0;
 static int g_head_table = 2;  // head section in global memory: 2 = the folded table when the program has one, 1 = first levels in heap order, 0 = neither
@@ -34,7 +35,7 @@ extern "C" {
 int sim_first_hit(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                   uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -87,7 +88,7 @@ static int g_redos = 0;
 int sim_first_hit_staged(const rtx_scene_desc* desc, const double* rays, size_t n, double* t, double* normal, uint32_t* prim_id,
                          uint32_t* mat_id, uint8_t* front) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   Scene S = prog.host_view(*desc);
   if (g_near_margin > 0.0) S.near_margin = g_near_margin;
   if (!S.head_end && !S.tail_begin) return -1;
@@ -226,6 +227,7 @@ int sim_top_walks(void) { return g_top_walks; }        // head sections walked w
 int sim_order_redos(void) { return g_redos; }          // rays of the last staged walk that went through the fixed order again   // sections the last staged walk took nearer child first
 void sim_set_fuse_sphere_media(int on) { g_fuse_sphere_media = on != 0; }
 void sim_set_guard_box6(int on) { g_guard_box6 = on != 0; }
+void sim_set_light_table(int on) { g_light_table = on != 0; }   // boxes over the light leaves cull lights_pdf_value
 void sim_set_draw_first(int on) { g_draw_first = on != 0; }   // thin sphere-bounded media draw their free path first
 void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }
 
@@ -233,7 +235,7 @@ void sim_set_defer_last_section(int on) { g_defer_last_section = on != 0; }
 int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx_render_opts* o, double* accum,
                uint64_t* counters, int nthreads) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   if (nthreads < 1) nthreads = 1;
@@ -271,7 +273,7 @@ int sim_render(const rtx_scene_desc* desc, const rtx_camera_desc* cam, const rtx
 // bytes, len receives the per-ray lengths.
 void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, uint32_t cap, uint8_t* seq, uint32_t* len) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene S = prog.host_view(*desc);
   for (size_t i = 0; i < n; ++i) {
     const double* r = rays + 7 * i;
@@ -290,7 +292,7 @@ void sim_trace_steps(const rtx_scene_desc* desc, const double* rays, size_t n, u
 // Histogram of unit kinds of the compiled program (16 counters) + total units in counts[16].
 void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   for (int k = 0; k < 17; ++k) counts[k] = 0;
   for (size_t i = 0; i < prog.units.size();) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)prog.units[i]);
@@ -315,7 +317,7 @@ void sim_philox(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x3
 void sim_philox10(const uint32_t* c, const uint32_t* k, uint32_t* out) { philox4x32_r<10>(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* uvp, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -325,14 +327,17 @@ void sim_texture_value(const rtx_scene_desc* desc, uint32_t tex, const double* u
 }
 void sim_lights_pdf(const rtx_scene_desc* desc, const double* origin, const double* dirs, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
-  for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); }
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; ++i) { uint32_t pb = 0; out[i] = lights_pdf_value(*S, v3(origin), v3(dirs + 3 * i), pb); total += pb; }
+  g_last_probes = total;
 }
+uint64_t sim_last_probes(void) { return g_last_probes; }   // lights evaluated by the last sim_lights_pdf call
 void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_t seed, size_t n, double* out) {
   CompiledProgram prog;
-  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
   const Scene view = prog.host_view(*desc);
   const Scene* S = &view;
   for (size_t i = 0; i < n; ++i) {
@@ -349,7 +354,7 @@ void sim_lights_random(const rtx_scene_desc* desc, const double* origin, uint64_
 struct SimScene { CompiledProgram prog; Scene view; };
 void* sim_scene_new(const rtx_scene_desc* desc) {      // the compiled program of a description, kept for many probe calls
   SimScene* h = new SimScene();
-  h->prog.fuse_sphere_media = g_fuse_sphere_media; h->prog.draw_first_thin_media = g_draw_first; h->prog.defer_last_section = g_defer_last_section; h->prog.guard_box6 = g_guard_box6;
+  h->prog.fuse_sphere_media = g_fuse_sphere_media; h->prog.draw_first_thin_media = g_draw_first; h->prog.light_table = g_light_table; h->prog.defer_last_section = g_defer_last_section; h->prog.guard_box6 = g_guard_box6;
   h->prog.compile(*desc);
   h->view = h->prog.host_view(*desc);
   return h;

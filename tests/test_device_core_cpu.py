@@ -97,6 +97,47 @@ def test_light_pdf_bit_exact_vs_oracle(name):
     assert (a > 0).sum() > 100
 
 
+def test_many_lights_pdf_bit_exact_vs_oracle_through_the_light_table():
+    """The stress configuration's 64 light quads (hittable_list.rs:78-88 sums 64 quad pdfs): the device core evaluates
+    only the lights whose widened box the probe ray passes, found through a small tree over the lights - every other
+    term is exactly zero - and adds them in the list's order.  Bit for bit the oracle's sum, with and without the table,
+    from several origins, directions aimed at the lights and random ones; and the table does cut the work."""
+    go, gp = H.oracle_graph(), rt.Graph()
+    wo, lo, cam = scenes.build("stress", go, width=64, n_prims=20000, prefix="orc_", lib=H.oracle_lib())
+    wp, lp, _ = scenes.build("stress", gp, width=64, n_prims=20000)
+    desc = rt.flatten(gp, wp, lp)
+    assert desc.n_lights == 64
+    rng = np.random.default_rng(3)
+    lib = H.hostsim_lib()
+    lib.sim_last_probes.restype = C.c_uint64
+    centres = np.array([[desc.quads[desc.lights[i].idx].q[k] + 0.5 * (desc.quads[desc.lights[i].idx].u[k] + desc.quads[desc.lights[i].idx].v[k])
+                         for k in range(3)] for i in range(64)])
+    hits = 0
+    for origin in (np.array([0.0, 0.0, 0.0]), np.array([500.0, -300.0, 120.0]), centres[5] + np.array([0.3, 0.2, 40.0]), np.array([1e12, 0.0, 0.0])):
+        aimed = centres[rng.integers(0, 64, 1500)] + rng.normal(scale=1.5, size=(1500, 3)) - origin
+        aimed *= rng.uniform(0.1, 3.0, (1500, 1))
+        dirs = np.ascontiguousarray(np.concatenate([aimed, rng.normal(size=(500, 3)), np.eye(3), -np.eye(3), [[0.0, 0.0, 0.0], [np.nan, 1.0, 0.0]]]))
+        n = len(dirs)
+        a, b, c = np.empty(n), np.empty(n), np.empty(n)
+        H.oracle_lib().orc_pdf_value(go.session, lo, H.dptr(origin), H.dptr(dirs), n, H.dptr(a))
+        lib.sim_lights_pdf(C.byref(desc), H.dptr(origin), H.dptr(dirs), n, H.dptr(b))
+        with_table = lib.sim_last_probes()
+        try:
+            lib.sim_set_light_table(0)
+            lib.sim_lights_pdf(C.byref(desc), H.dptr(origin), H.dptr(dirs), n, H.dptr(c))
+            without = lib.sim_last_probes()
+        finally:
+            lib.sim_set_light_table(1)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and np.array_equal(a.view(np.uint64), c.view(np.uint64))
+        assert without == 64 * n
+        if origin[0] < 1e11:
+            assert with_table < without // 8, (with_table, without)
+        else:
+            assert with_table == without        # too far out for the table's margin: every light is evaluated
+        hits += int((a > 0).sum())
+    assert hits > 1000
+
+
 def test_light_samples_hit_the_light():
     """lights.random(origin): every generated direction has a positive light pdf (it points at a light)."""
     gp = rt.Graph()
@@ -155,7 +196,7 @@ def test_render_statistics_vs_oracle(name, width, samples):
     b, cb = H.hostsim_render(desc, cam, rt.render_opts(cam, sample_begin=0, sample_end=n, seed=4))
     assert ca["paths"] == cb["paths"] == cam.image_width * cam.image_height * n
     assert abs(ca["segments"] / cb["segments"] - 1) < 0.03
-    assert 0.78 < (cb["pdf_probes"] + 1) / (ca["pdf_probes"] + 1) < 1.03
+    assert 0.78 < (cb["pdf_probes"] + 1) / (ca["pdf_probes"] + 1) < 1.03    # (fewer than 8 lights: every light is evaluated)
     assert np.isfinite(b).all()
     ma, mb = a.mean(axis=(0, 1)), b.mean(axis=(0, 1))
     assert np.abs(ma / mb - 1).max() < 0.03 + 0.3 / math.sqrt(n), (ma, mb)
