@@ -1327,6 +1327,22 @@ RT_HD RT_NOINLINE WideBest wide_walk_records(const uint64_t* prog, const rtx_qua
   return b;
 }
 
+#ifndef RT_WIDE_MIN_LANES
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_WIDE_MIN_LANES 12   // lanes that must wait for a kind of step before the wave computes it, unless it is the most wanted kind (stress scene: 0: 192, 8: 207, 12: 211, 16: 208, 24: 201 Msamples/s)
+#else
+#define RT_WIDE_MIN_LANES 0
+#endif
+#endif
+#ifndef RT_WIDE_MIN_NODE
+#define RT_WIDE_MIN_NODE RT_WIDE_MIN_LANES
+#endif
+#ifndef RT_WIDE_MIN_LEAF
+#define RT_WIDE_MIN_LEAF RT_WIDE_MIN_LANES
+#endif
+#ifndef RT_WIDE_MIN_QUAD
+#define RT_WIDE_MIN_QUAD RT_WIDE_MIN_LANES
+#endif
 #ifndef RT_WIDE_REFILL
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WIDE_REFILL 16   // lanes out of work at which the wave takes new rays
@@ -1415,7 +1431,18 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
     }
     // every lane's read: 16 units, at 16-byte granularity from the table of records or of quads, or of the program
     // from the box record in front of a leaf's units on
-    const bool on_node = have && st == ST_NODE, on_leaf = have && st == ST_LEAF, on_quad = QUADS && have && st == ST_QUAD;
+    bool on_node = have && st == ST_NODE, on_leaf = have && st == ST_LEAF, on_quad = QUADS && have && st == ST_QUAD;
+#if RT_WIDE_MIN_LANES > 0
+    {
+      // A kind of step is computed in this trip only when enough lanes wait for it to be worth the wave's time, or when
+      // it is the kind most lanes wait for; the other lanes keep their place (and issue no read) until a later trip.
+      const int n_node = RT_WAVE_COUNT(on_node), n_leaf = RT_WAVE_COUNT(on_leaf), n_quad = RT_WAVE_COUNT(on_quad);
+      const int top = n_node > n_leaf ? (n_node > n_quad ? n_node : n_quad) : (n_leaf > n_quad ? n_leaf : n_quad);
+      if (n_node < RT_WIDE_MIN_NODE && n_node < top) on_node = false;
+      if (n_leaf < RT_WIDE_MIN_LEAF && n_leaf < top) on_leaf = false;
+      if (n_quad < RT_WIDE_MIN_QUAD && n_quad < top) on_quad = false;
+    }
+#endif
     uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
 RT_UNROLL
     for (int k = 0; k < 16; ++k) blob[k] = 0ull;
