@@ -302,6 +302,15 @@ void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   counts[16] = (uint32_t)prog.units.size();
 }
 
+// Layout of the compiled program: units of the program, head_end, tail_begin, units with the tables behind it,
+// general media, head/tail nearer-child-first depths, light table nodes.
+void sim_program_layout(const rtx_scene_desc* desc, uint32_t* out8) {
+  CompiledProgram prog;
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  out8[0] = prog.prog_units; out8[1] = prog.head_end; out8[2] = prog.tail_begin; out8[3] = (uint32_t)prog.units.size();
+  out8[4] = prog.n_general_media; out8[5] = prog.head_near_depth; out8[6] = prog.tail_near_depth; out8[7] = (uint32_t)prog.light_nodes.size();
+}
+
 void sim_resolve_rgb8(const double* accum, int w, int h, int spp, uint8_t* rgb) {
   double scale = 1.0 / (double)spp;
   for (size_t i = 0; i < (size_t)w * (size_t)h * 3; ++i) rgb[i] = resolve_channel(accum[i], scale);
