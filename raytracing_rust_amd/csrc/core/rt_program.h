@@ -42,7 +42,11 @@ struct CompiledProgram {
   uint32_t n_general_media = 0;    // MEDIUM units emitted (media whose boundary needs a program of its own)
   bool guard_box6 = true;          // a widened box test in front of every BOX6 (tests switch it off to compare)
   bool fuse_sphere_media = true;   // emit MEDIUM_S for sphere-bounded media (tests switch it off to compare)
-  bool draw_first_thin_media = true;   // MEDIUM_S of a thin medium draws its free path before intersecting (same)
+  // MEDIUM_S of a thin medium draws its free path before it intersects the boundary and leaves early when the path is
+  // longer than the ray can be inside (exact: see walk_program).  Off by default: every walker here steps the 64 rays of
+  // a wave through a medium together, some lane always needs the boundary, and the wave then pays for both (final
+  // scene: 2268 against 2269 Msamples/s, 2 % more VALU instructions in the world-program kernel).  Tests switch it on.
+  bool draw_first_thin_media = false;
   bool defer_last_section = true;  // split the last top-level box subtree off into a program of its own (same)
   uint32_t tail_begin = 0;         // first unit of that program, 0 = none
   uint32_t tail_near_depth = 0;    // > 0: that program is a binary tree of boxes of this depth (walk_stream_near's shape)

@@ -23,7 +23,7 @@ static thread_local std::vector<double>* g_ray_log = nullptr;
 
 using namespace rt;
 
-static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true, g_draw_first = true, g_light_table = true;  // compile options under test
+static bool g_fuse_sphere_media = true, g_defer_last_section = true, g_guard_box6 = true, g_draw_first = false, g_light_table = true;  // compile options under test
 static uint64_t g_last_probes = 0;
 static int g_near_walks = 0, g_top_walks = 0, g_wide_walks = 0;
 static double g_near_margin = 0.0;

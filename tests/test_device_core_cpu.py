@@ -314,7 +314,7 @@ def test_thin_media_drawn_first_are_bit_identical(name, width):
         lib.sim_set_draw_first(1)
         b, cb = H.hostsim_render(desc, cam, opts)
     finally:
-        lib.sim_set_draw_first(1)
+        lib.sim_set_draw_first(0)
     assert ca == cb
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     assert a.sum() > 0

@@ -179,6 +179,29 @@ def test_stress_scene_render_path_at_full_size(gpu_ctx):
     scene.close()
 
 
+def test_thin_media_drawn_first_trace_the_same_paths(gpu_ctx, monkeypatch):
+    """RTX_MEDIA_DRAW_FIRST=1 compiles the final scene's fog (radius 5000, density 1e-4) so that it draws its free path
+    before it intersects its boundary and leaves when the path is longer than the ray can be inside
+    (constant_medium.rs:60-78 returns false then whatever the crossings are).  Same paths as the default form, in both
+    pipelines."""
+    gp = rt.Graph()
+    wp, lp, cam = scenes.build("final", gp, width=160, spp=16, depth=40)
+    desc = rt.flatten(gp, wp, lp)
+    plain = rt.Scene(gpu_ctx, desc)
+    monkeypatch.setenv("RTX_MEDIA_DRAW_FIRST", "1")
+    first = rt.Scene(gpu_ctx, desc)
+    monkeypatch.delenv("RTX_MEDIA_DRAW_FIRST")
+    for pipe in (_capi.PIPELINE_WAVEFRONT, _capi.PIPELINE_FUSED):
+        out = []
+        for scene in (plain, first):
+            gpu_ctx.reset_stats()
+            out.append((scene.render(cam, rt.render_opts(cam, seed=83, pipeline=pipe)), gpu_ctx.stats()))
+        (a, sa), (b, sb) = out
+        assert sa["segments"] == sb["segments"] and sa["pdf_probes"] == sb["pdf_probes"] and sa["segments"] > 2 * sa["paths"]
+        np.testing.assert_allclose(b, a, rtol=1e-11, atol=1e-13)
+    plain.close(); first.close()
+
+
 def test_texture_probe_first_bounce_matches_oracle(gpu_ctx):
     """Checker (checker.rs:41-56), a checker of a checker with noise and image children, marble noise at two scales
     (texture/noise.rs:29-35), the earth image, a missing image (cyan) - each as the emission of a light, rendered with

@@ -78,7 +78,18 @@ def test_light_sampling_replayed(name):
     assert (picked_sphere > 500) == (name == "cornell")
 
 
-def _both(name, **kw):
+def _both(name, draw_first=False, **kw):
+    """draw_first: compile thin sphere-bounded media so that they draw their free path before they intersect the
+    boundary (off by default); the device core then asks for a medium's number at every visit, the oracle only when the
+    ray crosses the boundary - the places the oracle never drew for hold fillers that must not change anything."""
+    H.hostsim_lib().sim_set_draw_first(1 if draw_first else 0)
+    try:
+        return _both_build(name, **kw)
+    finally:
+        H.hostsim_lib().sim_set_draw_first(0)
+
+
+def _both_build(name, **kw):
     go, gp = H.oracle_graph(), rt.Graph()
     wo, lo, cam = scenes.build(name, go, prefix="orc_", lib=H.oracle_lib(), **kw)
     wp, lp, _ = scenes.build(name, gp, **kw)
@@ -86,13 +97,14 @@ def _both(name, **kw):
     return go, wo, lo, R.DeviceScene(desc, keep=gp), cam, desc
 
 
-@pytest.mark.parametrize("name,width,depth,n_paths", [("cornell", 48, 50, 1200), ("smoke", 48, 50, 800), ("final", 64, 75, 1500),
-                                                      ("final", 64, 3, 600)])
-def test_whole_paths_replayed(name, width, depth, n_paths):
+@pytest.mark.parametrize("name,width,depth,n_paths,draw_first", [("cornell", 48, 50, 1200, False), ("smoke", 48, 50, 800, False),
+                                                                 ("final", 64, 75, 1500, False), ("final", 64, 3, 600, False),
+                                                                 ("final", 64, 75, 1500, True)])
+def test_whole_paths_replayed(name, width, depth, n_paths, draw_first):
     """Camera paths of the shipped scenes, ray_color of the oracle (recursion, camera.rs:167-247) against the device
     core's loop with the same numbers: the same rays bit for bit at every bounce - which pins every scatter, every
     sampled direction, every pdf rejection, every free path and the roulette - and the same radiance to 1e-12."""
-    go, wo, lo, dev, cam, desc = _both(name, width=width, spp=16, depth=depth)
+    go, wo, lo, dev, cam, desc = _both(name, draw_first=draw_first, width=width, spp=16, depth=depth)
     rng = np.random.default_rng(77)
     kinds = np.zeros(8, dtype=np.int64)
     segments = 0
