@@ -197,7 +197,23 @@ struct CompiledProgram {
     prog_units = (uint32_t)units.size();
     build_head_top();
     build_head_wide();
+    // can the stretch of the world program that the wavefront pipeline walks per ray (behind the head section, up to the
+    // deferred section) be swept by a wave in step (walk_flat)?
+    main_flat = false;
+    if (flat_walk) {
+      uint32_t boxes = 0;
+      bool ok = true;
+      for (uint32_t i = head_end ? head_end + 1u : world_begin; i < prog_units && ok; i += prog_record_units(units[i])) {
+        const uint32_t k = RTX_NODE_KIND((uint32_t)units[i]);
+        if (k == PROG_NODE_END) break;
+        if (k == RTX_NODE_MEDIUM) ok = false;
+        if (k == RTX_NODE_BOX) ++boxes;
+      }
+      main_flat = ok && boxes <= 16u;
+    }
   }
+  bool main_flat = false;
+  bool flat_walk = true;           // look for such a stretch (tests switch it off to compare)
 
   // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
   Scene host_view(const rtx_scene_desc& d) const {
@@ -213,6 +229,7 @@ struct CompiledProgram {
     S.light_nodes = light_nodes.data(); S.n_light_nodes = (uint32_t)light_nodes.size();
     S.n_light_groups = light_group_begin.empty() ? 0u : (uint32_t)light_group_begin.size() - 1u;
     S.light_group_begin = light_group_begin.data(); S.light_far = light_far;
+    S.main_flat = main_flat ? 1u : 0u; S._pad_flat = 0u;
     return S;
   }
 

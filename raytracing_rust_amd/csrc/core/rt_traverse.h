@@ -78,6 +78,8 @@ struct Scene : rtx_scene_desc {
   uint32_t n_light_nodes, n_light_groups;
   const uint32_t* light_group_begin;   // n_light_groups + 1 node positions
   double light_far;     // the table serves probe origins whose coordinates are within this
+  uint32_t main_flat;   // the world program behind its head section (all of it without one) up to its deferred section can
+  uint32_t _pad_flat;   // be walked by walk_flat: no general MEDIUM unit, at most a few boxes
   // Top of the head section's box tree, for a walk of a program that stays in global memory: copies of the box records
   // of its first levels in heap order (root 0, children of h at 2h+1 and 2h+2), 7 units each, at unit head_top_begin of
   // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none;
@@ -453,7 +455,8 @@ template <int MEDIA, bool DEFER, class RaySrc>
 RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                         double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                         double* stale_uv, uint32_t kind0 = RTX_NODE_MAKE(RTX_NODE_NONE, 0), uint32_t ctx0 = 0,
-                        bool have_start = false, V3 start_o = V3(), V3 start_d = V3()) {
+                        bool have_start = false, V3 start_o = V3(), V3 start_d = V3(), uint32_t stop_at = 0) {
+  // stop_at: a unit (in the world context, outside every box subtree) at which the walk ends as at an END; 0 = none
   enum { CL_CHEAP = 0, CL_SPHERE_S = 1, CL_QUAD_AA = 2, CL_SPHERE = 3, CL_QUAD = 4, CL_MEDIUM_EVAL = 5, CL_SYNC = 6, CL_BOX6 = 7, CL_BOX = 8, CL_MEDIUM_S = 9 };
   uint32_t cur = 0;
   uint32_t ret_tail = 0;  // DEFER = false: where to continue after the deferred program's END (0 = not inside it)
@@ -473,6 +476,10 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
   uint64_t unit = running ? prog[i] : (uint64_t)RTX_NODE_MAKE(PROG_NODE_END, 0);
   RT_PROF_START();
   while (RT_WAVE_ANY(running)) {
+    if (stop_at != 0) {   // (a lane gets here through a skip link, a box step or the unit before)
+      if (running && i == stop_at) running = false;
+      if (!RT_WAVE_ANY(running)) break;
+    }
     const uint32_t kind_idx = (uint32_t)unit;
     const uint32_t kind = RTX_NODE_KIND(kind_idx), idx = RTX_NODE_IDX(kind_idx), count = (uint32_t)(unit >> 32);
     int cls = CL_CHEAP;
@@ -679,6 +686,156 @@ RT_UNROLL
       // the END of the outermost program ends the walk at once (no trip of its own)
       if (RTX_NODE_KIND((uint32_t)unit) == PROG_NODE_END && (MEDIA != MEDIA_ALL || mode == 0) && (DEFER || ret_tail == 0)) running = false;
     }
+  }
+  best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
+  return deferred;
+}
+
+// walk_program<MEDIA, true> for a stretch of the program that every ray of a wave passes unit by unit together - a
+// top-level list of primitives, sphere-bounded media and transforms with at most a few boxes in it
+// (CompiledProgram::main_flat) - from unit `begin` to the END.  ONE position for the whole wave: the unit is read once
+// and decoded in scalar registers, every lane that is not inside a box it failed takes the step, and nothing is voted
+// on.  A lane that fails a box sits out until the sweep reaches the box's skip target (subtrees nest, so a lane's target
+// is never passed over).  Per ray the same units in the same order with the same running tmax as walk_program: the
+// same result bit for bit.  No general MEDIUM units (the caller checks); MEDIA: MEDIA_NONE or MEDIA_SPHERES.
+template <int MEDIA, class RaySrc>
+RT_HD bool walk_flat(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
+                     double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
+                     double* stale_uv, uint32_t kind0, uint32_t ctx0, bool have_start, V3 start_o, V3 start_d) {
+  uint32_t cur = 0, skip_until = 0;     // skip_until: unit at which this lane joins in again (0 = it is in)
+  bool deferred = false;
+  LRay lr;
+  lr.o = v3(0, 0, 0); lr.d = v3(0, 0, 1); lr.inv = v3(0, 0, 1); lr.skip = 0;
+  if (active) lr = have_start ? lray_from_ops(prog, 0, start_o, start_d) : lray_from_ops(prog, 0, rs.origin(), rs.dir());
+  const double tmin = tmin0;
+  double tmax = tmax0;
+  uint32_t hit_kind = kind0, hit_ctx = ctx0;
+  uint32_t i = begin;
+  if (!RT_WAVE_ANY(active)) { best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx; return false; }
+  // the header of a unit in scalar registers (every lane reads the same word)
+  auto header = [&](uint32_t at) -> uint64_t {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t v = prog[at];
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+#else
+    return prog[at];
+#endif
+  };
+  uint64_t unit = header(i);
+  for (;;) {
+    const uint32_t kind = RTX_NODE_KIND((uint32_t)unit), idx = RTX_NODE_IDX((uint32_t)unit), count = (uint32_t)(unit >> 32);
+    if (kind == PROG_NODE_END) break;
+    if (skip_until != 0 && skip_until <= i) skip_until = 0;
+    const bool on = active && skip_until == 0;
+    uint32_t next = kind == PROG_NODE_DEFER ? i + 1u : i + prog_record_units(unit);
+    // the header of the unit behind this one is read while this one is computed (a box that nobody passes goes elsewhere)
+    const uint64_t unit_behind = prog[next];
+    if (kind == RTX_NODE_BOX) {
+      bool pass = false;
+      if (on) {
+        RT_TRACE_STEP(RTX_NODE_BOX);
+        pass = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax);
+        if (!pass) skip_until = count;
+      }
+      if (!RT_WAVE_ANY(pass)) { next = count; unit = header(next); i = next; continue; }   // nobody goes in: every lane that was in waits at the skip target, the others beyond it
+    } else if (kind == PROG_NODE_SPHERE_S) {
+      if (on) {
+        for (uint32_t k = 0; k < count; ++k) {
+          double t;
+          const DSphere sp = *(const DSphere*)(prog + i + 1 + PROG_SPHERE_S_UNITS * k);
+          if (sphere_s_hit_t(sp, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx + k); hit_ctx = cur; }
+        }
+        RT_TRACE_STEP(32u + 1u);
+      }
+    } else if (kind == PROG_NODE_QUAD_AA || kind == PROG_NODE_BOX6 || kind == RTX_NODE_QUAD) {
+      if (on) {
+        const uint32_t cnt = kind == PROG_NODE_QUAD_AA ? count : (kind == PROG_NODE_BOX6 ? 6u : 1u);
+        if (kind == RTX_NODE_QUAD || (lr.skip & 8u)) {   // a general quad, or a compact record met by a ray with non-finite components
+          for (uint32_t k = 0; k < cnt; ++k) {
+            double t;
+            if (quad_hit_t(S.quads[idx + k], lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+        } else if (kind == PROG_NODE_BOX6) {
+          const DBox6 bx = *(const DBox6*)(prog + i + 1);
+RT_UNROLL
+          for (int f = 0; f < 6; ++f) {
+            double t;
+            if (aaquad_hit_t(box6_face(bx, f), lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + (uint32_t)f); hit_ctx = cur; }
+          }
+        } else {
+          for (uint32_t k = 0; k < cnt; ++k) {
+            double t;
+            const DAAQuad qa = *(const DAAQuad*)(prog + i + 1 + PROG_QUAD_AA_UNITS * k);
+            if (aaquad_hit_t(qa, lr.o, lr.d, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_QUAD, idx + k); hit_ctx = cur; }
+          }
+        }
+        RT_TRACE_STEP(32u + 2u);
+      }
+    } else if (kind == RTX_NODE_SPHERE) {
+      if (on) {
+        double t;
+        if (sphere_rec_hit_t((const double*)(prog + i + 1), lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
+        RT_TRACE_STEP(32u + 3u);
+      }
+    } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+      if (on) {
+        const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();   // as in walk_program
+        cur = idx;
+        lr = lray_from_ops(prog + i + 1, count, wo, wd);
+        RT_TRACE_STEP(kind);
+      }
+    } else if (MEDIA != MEDIA_NONE && kind == PROG_NODE_MEDIUM_S && use_media) {
+      if (on) {   // constant_medium.rs:42-90 for a boundary of one static sphere: as the MEDIUM_S step of walk_program
+        const double neg_inv_density = ((const double*)prog)[i + 1];
+        const uint64_t mflags = prog[i + 2];
+        const DSphere sp = *(const DSphere*)(prog + i + 3);
+        double t_in = 0.0, t_out = 0.0, ray_length = 0.0, hit_distance = 0.0;
+        bool crossed = true, drawn = false;
+        if ((mflags & PROG_MEDIUM_DRAW_FIRST) && tmin0 >= 0.0) {
+          ray_length = norm(lr.d);
+          hit_distance = neg_inv_density * log(rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), idx));
+          drawn = true;
+          bool beyond = hit_distance > tmax * ray_length;
+          if (!beyond) {
+            const V3 oc = lr.o - v3(sp.cx, sp.cy, sp.cz);
+            beyond = norm2(oc) <= 1e4 * (sp.r * sp.r) && hit_distance > (2.0 * sp.r) * (1.0 + 1e-9);
+          }
+          crossed = !beyond;
+        }
+        crossed = crossed && sphere_s_hit_t(sp, lr.o, lr.d, -RT_INF, RT_INF, t_in) && sphere_s_hit_t(sp, lr.o, lr.d, t_in + 0.0001, RT_INF, t_out);
+        if (crossed) {
+          double t1 = fmax(t_in, tmin0);
+          double t2 = fmin(t_out, tmax);
+          if (!(t1 >= t2)) {
+            t1 = fmax(t1, 0.0);
+            if (!drawn) {
+              ray_length = norm(lr.d);
+              hit_distance = neg_inv_density * log(rng_at(rng, bounce | ((uint32_t)RNG_DOMAIN_MEDIUM << 16), idx));
+            }
+            const double inside = (t2 - t1) * ray_length;
+            if (!(hit_distance > inside)) {
+              if ((mflags & PROG_MEDIUM_NEEDS_UV) && stale_uv) {
+                const uint64_t id = (uint64_t)hit_kind | ((uint64_t)hit_ctx << 32);
+                stale_uv[0] = tmax;
+                memcpy(&stale_uv[1], &id, 8);
+              }
+              tmax = t1 + hit_distance / ray_length;
+              hit_kind = RTX_NODE_MAKE(RTX_NODE_MEDIUM, idx); hit_ctx = cur;
+            }
+          }
+        }
+        RT_TRACE_STEP(32u + 9u);
+      }
+    } else if (kind == PROG_NODE_DEFER) {
+      if (on) deferred = true;
+    }
+    // (filler, SYNC, a medium this query ignores: nothing to do)
+    i = next;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unit = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unit_behind >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)unit_behind);
+#else
+    unit = unit_behind;
+#endif
   }
   best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
   return deferred;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_wf_raygen(rtx_camera_desc cam, WfFrame 
 //
 // MM (MEDIA_NONE / MEDIA_SPHERES / MEDIA_ALL) is what the world program needs for its media: a program without
 // general MEDIUM units runs the variant without the boundary-program machinery, which saves it registers.
-template <bool USE_LDS, bool TAIL, int MM, bool GEN = false>
+template <bool USE_LDS, bool TAIL, int MM, bool GEN = false, bool FLAT = false>   // FLAT: the variant for a program whose stretch behind the head section is swept in step (Scene::main_flat)
 __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32_t cap, unsigned long long seed, WfCounters* c,
                                                       WfQueue q, WfHits h, uint32_t* __restrict__ defer_list,
                                                       unsigned long long* __restrict__ stats, rtx_camera_desc cam, WfFrame fr) {
@@ -313,8 +313,27 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
       const double t0 = behind ? h.t[idx] : RT_INF;
       RT_KPROF_ADD(14, kp_pass);
       const uint32_t kind0 = behind ? h.kind_idx[idx] : (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), ctx0 = behind ? h.ctx[idx] : 0u;
-      const bool deferred = walk_program<MM, true>(S, prog, behind ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
-                                                   MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0, gen, nray.o, nray.d);
+      bool deferred;
+      if (FLAT && MM != MEDIA_ALL) {
+        // the stretch behind the head section is a list every ray passes unit by unit: the wave sweeps it in step
+        // (walk_flat); lanes that have not been through the head section (new camera paths) walk that first
+        double t1 = t0;
+        uint32_t kind1 = kind0, ctx1 = ctx0;
+        if (S.head_end != 0) {
+          const bool fresh = active && !behind;
+          if (RT_WAVE_ANY(fresh)) {
+            Hit hh;
+            walk_program<MEDIA_NONE, true>(S, prog, S.world_begin, fresh, rs, tm, 0.001, RT_INF, hh, false, rng, bounce, nullptr,
+                                           (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, gen, nray.o, nray.d, S.head_end);
+            if (fresh) { t1 = hh.t; kind1 = hh.kind_idx; ctx1 = hh.ctx; }
+          }
+        }
+        deferred = walk_flat<MM>(S, prog, S.head_end ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t1, hit, MM != MEDIA_NONE,
+                                 rng, bounce, h.uv + 2 * (size_t)idx, kind1, ctx1, gen, nray.o, nray.d);
+      } else {
+        deferred = walk_program<MM, true>(S, prog, behind ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
+                                          MM != MEDIA_NONE, rng, bounce, h.uv + 2 * (size_t)idx, kind0, ctx0, gen, nray.o, nray.d);
+      }
       if (active) { h.t[idx] = hit.t; h.kind_idx[idx] = hit.kind_idx; h.ctx[idx] = hit.ctx; }
       RT_KPROF_ADD(11, kp_pass);
       if (collect) {
@@ -1182,6 +1201,8 @@ static hipError_t wf_set_lds_limits() {
   const void* kernels[] = {
       (const void*)k_wf_traverse<true, false, MEDIA_NONE>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES>, (const void*)k_wf_traverse<true, false, MEDIA_ALL>,
       (const void*)k_wf_traverse<true, false, MEDIA_NONE, true>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES, true>, (const void*)k_wf_traverse<true, false, MEDIA_ALL, true>,
+      (const void*)k_wf_traverse<true, false, MEDIA_NONE, true, true>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES, true, true>,
+      (const void*)k_wf_traverse<true, false, MEDIA_NONE, false, true>, (const void*)k_wf_traverse<true, false, MEDIA_SPHERES, false, true>,
       (const void*)k_wf_traverse<false, false, MEDIA_NONE>, (const void*)k_wf_traverse<false, false, MEDIA_SPHERES>, (const void*)k_wf_traverse<false, false, MEDIA_ALL>,
       (const void*)k_wf_traverse<true, true, MEDIA_NONE>, (const void*)k_wf_traverse<false, true, MEDIA_NONE>,
       (const void*)k_wf_stream<true, false, 0>, (const void*)k_wf_stream<false, false, 0>, (const void*)k_wf_stream<true, false, 2>, (const void*)k_wf_stream<false, false, 2>,
@@ -1354,6 +1375,10 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
   // A world that is one large BVH is all head section: the head stream leaves every path's closest hit in the hit
   // arrays, and a world-program launch would only read and rewrite them (stress scene: 23 % of the GPU time).
   P.skip_main = head_end != 0 && P.dev.fresh_in_main == 0u && sc->nothing_behind_head;
+  const bool flat = sc->dev.main_flat != 0 && mm != MEDIA_ALL && P.main_lds;   // (a program walked from global memory keeps the per-ray walk)
+  if (flat) P.k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true, true> : k_wf_traverse<true, false, MEDIA_SPHERES, true, true>)
+                                   : (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, false, true> : k_wf_traverse<true, false, MEDIA_SPHERES, false, true>);
+  else
   P.k_main = gen_in_main ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE, true> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES, true> : k_wf_traverse<true, false, MEDIA_ALL, true>)
            : P.main_lds ? (mm == MEDIA_NONE ? k_wf_traverse<true, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<true, false, MEDIA_SPHERES> : k_wf_traverse<true, false, MEDIA_ALL>)
                         : (mm == MEDIA_NONE ? k_wf_traverse<false, false, MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_traverse<false, false, MEDIA_SPHERES> : k_wf_traverse<false, false, MEDIA_ALL>);
@@ -1680,6 +1705,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   CompiledProgram prog;
   if (const char* e = getenv("RTX_MEDIA_DRAW_FIRST")) prog.draw_first_thin_media = atoi(e) != 0;   // tuning knob: 0 = thin media intersect first too
   if (const char* e = getenv("RTX_LIGHT_TABLE")) prog.light_table = atoi(e) != 0;                  // tuning knob: 0 = every light is evaluated
+  if (const char* e = getenv("RTX_FLAT_WALK")) prog.flat_walk = atoi(e) != 0;                      // tuning knob: 0 = no wave-uniform sweep of flat stretches
   prog.compile(*d);
   rtx_scene* sc = new rtx_scene();
   sc->ctx = ctx;
@@ -1704,6 +1730,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.n_light_nodes = (uint32_t)prog.light_nodes.size();
   sc->dev.n_light_groups = prog.light_group_begin.empty() ? 0u : (uint32_t)prog.light_group_begin.size() - 1u;
   sc->dev.light_far = prog.light_far;
+  sc->dev.main_flat = prog.main_flat ? 1u : 0u; sc->dev._pad_flat = 0u;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.light_nodes.data(), prog.light_nodes.size(), &sc->dev.light_nodes);
   if (st == RTX_OK) st = upload(sc, prog.light_group_begin.data(), prog.light_group_begin.size(), &sc->dev.light_group_begin);

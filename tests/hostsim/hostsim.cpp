@@ -302,6 +302,45 @@ void sim_program_stats(const rtx_scene_desc* desc, uint32_t* counts) {
   counts[16] = (uint32_t)prog.units.size();
 }
 
+// walk_flat against walk_program: the closest hit of every ray through the stages the wavefront pipeline walks (head
+// section by walk_program up to its end, the flat stretch by walk_flat, the deferred section as a call) against the
+// undivided walk, media included (free paths addressed by the ray's number).  Returns the number of rays whose hit
+// (t, kind, context, stale (u, v) record) differs; -1 when the program has no flat stretch.
+long sim_check_flat_walk(const rtx_scene_desc* desc, const double* rays, size_t n, uint32_t bounce, size_t* n_hits, size_t* n_media_hits) {
+  CompiledProgram prog;
+  prog.fuse_sphere_media = g_fuse_sphere_media; prog.draw_first_thin_media = g_draw_first; prog.light_table = g_light_table; prog.defer_last_section = g_defer_last_section; prog.guard_box6 = g_guard_box6; prog.compile(*desc);
+  const Scene S = prog.host_view(*desc);
+  if (!S.main_flat || prog.n_general_media != 0) return -1;
+  long bad = 0;
+  size_t hits = 0, media = 0;
+  const uint32_t none = (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0);
+  for (size_t k = 0; k < n; ++k) {
+    const double* r = rays + 7 * k;
+    RayRegs rs;
+    rs.r.o = v3(r[0], r[1], r[2]); rs.r.d = v3(r[3], r[4], r[5]); rs.r.tm = r[6];
+    const PathRng rng = rng_make(991, (uint32_t)k, 3);
+    Hit a, b, hh;
+    double uva[2] = {0.0, 0.0}, uvb[2] = {0.0, 0.0};
+    closest_hit<true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, a, true, rng, bounce, uva);
+    hh.t = RT_INF; hh.kind_idx = none; hh.ctx = 0;
+    if (S.head_end) walk_program<MEDIA_NONE, true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, hh, false, rng, bounce, nullptr, none, 0u, false, V3(), V3(), S.head_end);
+    const bool deferred = walk_flat<MEDIA_SPHERES>(S, S.prog, S.head_end ? S.head_end + 1u : S.world_begin, true, rs, r[6], 0.001, hh.t, b, true, rng, bounce, uvb,
+                                                   hh.kind_idx, hh.ctx, false, V3(), V3());
+    if (deferred && S.tail_begin) {
+      Hit h2;
+      walk_program<MEDIA_NONE, false>(S, S.prog, S.tail_begin, true, rs, r[6], 0.001, b.t, h2, false, rng, bounce, uvb);
+      if (hit_any(h2)) b = h2;
+    }
+    const bool same = memcmp(&a.t, &b.t, 8) == 0 && a.kind_idx == b.kind_idx && (!hit_any(a) || a.ctx == b.ctx) && memcmp(uva, uvb, 16) == 0;
+    if (!same) ++bad;
+    if (hit_any(a)) ++hits;
+    if (RTX_NODE_KIND(a.kind_idx) == RTX_NODE_MEDIUM) ++media;
+  }
+  if (n_hits) *n_hits = hits;
+  if (n_media_hits) *n_media_hits = media;
+  return bad;
+}
+
 // Layout of the compiled program: units of the program, head_end, tail_begin, units with the tables behind it,
 // general media, head/tail nearer-child-first depths, light table nodes.
 void sim_program_layout(const rtx_scene_desc* desc, uint32_t* out8) {

@@ -243,3 +243,30 @@ def test_unsupported_graphs_are_rejected():
         g.bvh(g.list())                     # the reference would index an empty slice
     with pytest.raises(rt.GraphError):
         g.sphere((0, 0, 0), 1.0, 9999)      # bad material handle
+
+
+@pytest.mark.parametrize("name", ["final", "cornell"])
+def test_flat_stretch_swept_in_step_is_the_same_walk(name):
+    """The stretch of the world program behind its head section is a list every ray passes unit by unit; the
+    wavefront pipeline's world-program kernel sweeps it with one position for the whole wave (walk_flat).  Stage by
+    stage (head section, flat stretch, deferred section) against the undivided walk: same hit bit for bit, media
+    included, on camera rays and on rays from inside the scene (which meet the media and the sphere cluster)."""
+    g = rt.Graph()
+    w, l, cam = scenes.build(name, g, width=96)
+    desc = rt.flatten(g, w, l)
+    rng = np.random.default_rng(17)
+    inside = np.concatenate([rng.uniform(-100, 600, (6000, 3)), rng.normal(size=(6000, 3)) * rng.uniform(0.1, 5.0, (6000, 1)),
+                             rng.uniform(0, 1, (6000, 1))], axis=1)
+    odd = np.array([[278.0, 278.0, -800.0, 0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], [278.0, 278.0, -800.0, np.nan, 0.0, 1.0, 0.5],
+                    [278.0, 278.0, -800.0, np.inf, 0.0, 1.0, 0.5], [1e12, 0.0, 0.0, -1.0, 0.0, 0.0, 0.2]])
+    rays = np.ascontiguousarray(np.concatenate([rt.pixel_center_rays(cam, time=0.4), inside, odd]))
+    lib = H.hostsim_lib()
+    lib.sim_check_flat_walk.restype = ctypes.c_long
+    lib.sim_check_flat_walk.argtypes = [ctypes.POINTER(_capi.SceneDesc), H.PD, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    hits, media = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    for bounce in (0, 4):
+        bad = lib.sim_check_flat_walk(ctypes.byref(desc), H.dptr(rays), len(rays), bounce, ctypes.byref(hits), ctypes.byref(media))
+        assert bad == 0, f"{bad} of {len(rays)} rays differ"
+        assert hits.value > len(rays) // 2
+        if name == "final":
+            assert media.value > 200
