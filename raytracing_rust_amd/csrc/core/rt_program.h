@@ -210,9 +210,11 @@ struct CompiledProgram {
         if (k == RTX_NODE_BOX) ++boxes;
       }
       main_flat = ok && boxes <= 16u;
+      flat_begin = head_end ? head_end + 1u : world_begin;
     }
   }
   bool main_flat = false;
+  uint32_t flat_begin = 0;         // first unit of that stretch (head_end + 1 whether or not the head section is streamed)
   bool flat_walk = true;           // look for such a stretch (tests switch it off to compare)
 
   // The scene as the traversal code sees it, over host memory (tables of `d`, program of this object).
@@ -229,7 +231,7 @@ struct CompiledProgram {
     S.light_nodes = light_nodes.data(); S.n_light_nodes = (uint32_t)light_nodes.size();
     S.n_light_groups = light_group_begin.empty() ? 0u : (uint32_t)light_group_begin.size() - 1u;
     S.light_group_begin = light_group_begin.data(); S.light_far = light_far;
-    S.main_flat = main_flat ? 1u : 0u; S._pad_flat = 0u;
+    S.main_flat = main_flat ? 1u : 0u; S.flat_begin = flat_begin;
     return S;
   }
 

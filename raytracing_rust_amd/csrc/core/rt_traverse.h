@@ -78,8 +78,8 @@ struct Scene : rtx_scene_desc {
   uint32_t n_light_nodes, n_light_groups;
   const uint32_t* light_group_begin;   // n_light_groups + 1 node positions
   double light_far;     // the table serves probe origins whose coordinates are within this
-  uint32_t main_flat;   // the world program behind its head section (all of it without one) up to its deferred section can
-  uint32_t _pad_flat;   // be walked by walk_flat: no general MEDIUM unit, at most a few boxes
+  uint32_t main_flat;   // the world program from unit flat_begin (behind its first large box subtree, or its start) up to its
+  uint32_t flat_begin;  // deferred section can be walked by walk_flat: no general MEDIUM unit, at most a few boxes
   // Top of the head section's box tree, for a walk of a program that stays in global memory: copies of the box records
   // of its first levels in heap order (root 0, children of h at 2h+1 and 2h+2), 7 units each, at unit head_top_begin of
   // the image, followed by the records' own unit positions (one uint32 each).  head_top_nodes = 2^levels - 1, 0 = none;

@@ -319,16 +319,16 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
         // (walk_flat); lanes that have not been through the head section (new camera paths) walk that first
         double t1 = t0;
         uint32_t kind1 = kind0, ctx1 = ctx0;
-        if (S.head_end != 0) {
+        if (S.flat_begin != S.world_begin) {   // (whether or not that section was streamed for the survivors: S.head_end)
           const bool fresh = active && !behind;
           if (RT_WAVE_ANY(fresh)) {
             Hit hh;
             walk_program<MEDIA_NONE, true>(S, prog, S.world_begin, fresh, rs, tm, 0.001, RT_INF, hh, false, rng, bounce, nullptr,
-                                           (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, gen, nray.o, nray.d, S.head_end);
+                                           (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, gen, nray.o, nray.d, S.flat_begin - 1u);
             if (fresh) { t1 = hh.t; kind1 = hh.kind_idx; ctx1 = hh.ctx; }
           }
         }
-        deferred = walk_flat<MM>(S, prog, S.head_end ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t1, hit, MM != MEDIA_NONE,
+        deferred = walk_flat<MM>(S, prog, S.flat_begin, active, rs, tm, 0.001, t1, hit, MM != MEDIA_NONE,
                                  rng, bounce, h.uv + 2 * (size_t)idx, kind1, ctx1, gen, nray.o, nray.d);
       } else {
         deferred = walk_program<MM, true>(S, prog, behind ? S.head_end + 1u : S.world_begin, active, rs, tm, 0.001, t0, hit,
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
 #ifndef RT_FINISH_THREADS
 #define RT_FINISH_THREADS 768   // (one workgroup per CU for its LDS: 512: quick 1095, 768: 1135, 1024: 1125 Msamples/s - the registers of shading spill, but more paths finish per round)
 #endif
-template <int MM>
+template <int MM, bool FLAT = false>   // FLAT: as in k_wf_traverse
 __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rtx_camera_desc cam, uint32_t cap, unsigned long long seed,
                                                                     int use_lights, uint32_t threshold, WfCounters* c, WfQueue qin,
                                                                     double* __restrict__ accum, unsigned long long* __restrict__ stats) {
@@ -860,7 +860,18 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
     if (alive) ++segs;
     RayRegs rs;
     rs.r = ray;
-    const bool deferred = walk_program<MM, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, ps.rng, ps.bounce, stale_uv);
+    bool deferred;
+    if (FLAT && MM != MEDIA_ALL) {
+      Hit hh;
+      hh.t = RT_INF; hh.kind_idx = (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0); hh.ctx = 0u;
+      if (S.flat_begin != S.world_begin)
+        walk_program<MEDIA_NONE, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hh, false, ps.rng, ps.bounce, nullptr,
+                                       (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, false, V3(), V3(), S.flat_begin - 1u);
+      deferred = walk_flat<MM>(S, lds_prog, S.flat_begin, alive, rs, ray.tm, 0.001, hh.t, hit, MM != MEDIA_NONE,
+                               ps.rng, ps.bounce, stale_uv, hh.kind_idx, hh.ctx, false, V3(), V3());
+    } else {
+      deferred = walk_program<MM, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, ps.rng, ps.bounce, stale_uv);
+    }
     if (tail_units) {
       __syncthreads();
       const uint4* src = (const uint4*)(S.prog + S.tail_begin);
@@ -1212,7 +1223,8 @@ static hipError_t wf_set_lds_limits() {
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e != hipSuccess) return e;
   }
-  const void* finishers[] = {(const void*)k_wf_finish_lds<MEDIA_NONE>, (const void*)k_wf_finish_lds<MEDIA_SPHERES>, (const void*)k_wf_finish_lds<MEDIA_ALL>};
+  const void* finishers[] = {(const void*)k_wf_finish_lds<MEDIA_NONE>, (const void*)k_wf_finish_lds<MEDIA_SPHERES>, (const void*)k_wf_finish_lds<MEDIA_ALL>,
+                             (const void*)k_wf_finish_lds<MEDIA_NONE, true>, (const void*)k_wf_finish_lds<MEDIA_SPHERES, true>};
   for (const void* k : finishers) {   // (this kernel also has a few bytes of static LDS)
     const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFinishLdsBudget);
     if (e != hipSuccess) return e;
@@ -1387,6 +1399,7 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
     const char* fe = getenv("RTX_WF_FINISH_LDS");   // 0: the finishing kernel walks the program in global memory
     if (whole_main <= kFinishLdsBudget && P.tail_bytes <= kFinishLdsBudget && !(fe && atoi(fe) == 0)) {
       P.k_finish_lds = mm == MEDIA_NONE ? k_wf_finish_lds<MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_finish_lds<MEDIA_SPHERES> : k_wf_finish_lds<MEDIA_ALL>;
+      if (sc->dev.main_flat != 0 && mm != MEDIA_ALL) P.k_finish_lds = mm == MEDIA_NONE ? k_wf_finish_lds<MEDIA_NONE, true> : k_wf_finish_lds<MEDIA_SPHERES, true>;
       P.finish_lds_bytes = std::max(whole_main, P.tail_bytes);
     }
   }
@@ -1730,7 +1743,7 @@ rtx_status rtx_scene_create(rtx_context* ctx, const rtx_scene_desc* d, rtx_scene
   sc->dev.n_light_nodes = (uint32_t)prog.light_nodes.size();
   sc->dev.n_light_groups = prog.light_group_begin.empty() ? 0u : (uint32_t)prog.light_group_begin.size() - 1u;
   sc->dev.light_far = prog.light_far;
-  sc->dev.main_flat = prog.main_flat ? 1u : 0u; sc->dev._pad_flat = 0u;
+  sc->dev.main_flat = prog.main_flat ? 1u : 0u; sc->dev.flat_begin = prog.flat_begin;
   rtx_status st = upload(sc, prog.units.data(), prog.units.size(), &sc->dev.prog);
   if (st == RTX_OK) st = upload(sc, prog.light_nodes.data(), prog.light_nodes.size(), &sc->dev.light_nodes);
   if (st == RTX_OK) st = upload(sc, prog.light_group_begin.data(), prog.light_group_begin.size(), &sc->dev.light_group_begin);
