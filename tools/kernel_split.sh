@@ -7,6 +7,8 @@ cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/split_$tag.txt
 : > $out
 for lib in "$@"; do
+  # an argument VAR=value sets the environment for the builds that follow
+  case "$lib" in *=*) export "$lib"; echo "env $lib" | tee -a $out; continue;; esac
   line=$(RTX_AMD_LIB=$lib timeout -k 10 150 python3 bench.py --steps 1 --warmup 1 --rows 10 --no-cpu-baseline --roofline-rows 10 | grep '^{') || { echo "run failed: $lib" | tee -a $out; exit 1; }
   echo "$lib" | tee -a $out
   echo "$line" | python3 -c '
