@@ -140,12 +140,13 @@ def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, tor
     own_shade = 16 + 108 * (1.0 - p_drop) + 92 * p_survive + 24 * max(0.0, 1.0 - p_survive - p_drop)
     # deferred rays are not counted by the library; one ray in nine enters the section in this scene (profiles/README.md)
     kernels = [
-        ("k_wf_traverse<true,false,1,true>", "world program + camera rays", st["traverse_ms"], APRIORI_TRAVERSE_BYTES, own_trav, "k_wf_traverse"),
+        ("k_wf_traverse<true,false,1,true,true>", "world program + camera rays", st["traverse_ms"], APRIORI_TRAVERSE_BYTES, own_trav, "k_wf_traverse"),
         ("k_wf_shade", "shading + compaction", st["shade_ms"], APRIORI_BOUNCE_BYTES - APRIORI_TRAVERSE_BYTES, own_shade, "k_wf_shade"),
         ("k_wf_stream<true,false,0>", "head section (ground BVH), survivors", st["head_ms"], APRIORI_TRAVERSE_BYTES, 72.0 * (1.0 - new_frac), "k_wf_stream_head"),
         ("k_wf_stream<true,true,1>", "deferred section (sphere cluster)", st["tail_ms"], APRIORI_TRAVERSE_BYTES / 9.0, 92.0 / 9.0, "k_wf_stream_deferred"),
     ]
     total_ms = sum(k[2] for k in kernels)
+    trav_ms = max(1e-9, sum(k[2] for k in kernels if k[5] != "k_wf_shade"))
     out = []
     for name, what, ms, survey_b, own_b, key in kernels:
         if ms <= 0.0:
@@ -172,6 +173,13 @@ def roofline_block(rt, ctx, scene, cam, accum, stream, rows, wall_seg_per_s, tor
         "pass": {"rows": rows, "wall_ms": wall_ms, "sum_kernel_ms": total_ms, "segments": seg, "paths": paths,
                  "Msegments_per_s": seg_s / 1e6, "Msamples_per_s": paths / (wall_ms * 1e-3) / 1e6},
         "other_kernels": out[1:],
+        # one world.hit of a segment is spread over three kernels (head section, world program, deferred section):
+        # the same 80 B per segment against the sum of their durations
+        "traversal_total": {"kernels": [k[0] for k in kernels if k[5] != "k_wf_shade" and k[2] > 0.0],
+                            "algorithmic_bytes_per_segment": APRIORI_TRAVERSE_BYTES, "gpu_ms": trav_ms,
+                            "achieved": seg * APRIORI_TRAVERSE_BYTES / (trav_ms * 1e-3) / 1e9,
+                            "frac": seg * APRIORI_TRAVERSE_BYTES / (trav_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                            "Msegments_per_s": seg / (trav_ms * 1e-3) / 1e6},
         "whole_bounce": {"note": "all kernels of a bounce over the WALL time of the timed region (all pipelines)",
                          "algorithmic_bytes_per_segment": APRIORI_BOUNCE_BYTES,
                          "achieved": wall_seg_per_s * APRIORI_BOUNCE_BYTES / 1e9, "frac": wall_seg_per_s * APRIORI_BOUNCE_BYTES / 1e9 / HBM_PEAK_GBS,

@@ -69,7 +69,7 @@ using namespace rt;
 // ================================================================ kernels ===
 
 #ifndef RT_SHADE_ATTR
-#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(2)))  // two waves per SIMD: 256 registers each, no more
+#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(2)))  // at least two waves per SIMD (up to 256 registers); it needs 160, so three run
 #endif
 #ifndef RT_TRAV_THREADS
 #define RT_TRAV_THREADS 1024  // threads of a traversal workgroup (one workgroup per CU)
@@ -480,7 +480,11 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 // pass on the counter's line is what used to bound this kernel).  The few entries that end after all (an absorbed
 // metal reflection, a rejected pdf, the last bounce) leave their slot as a DEAD entry: remaining depth 0 and a
 // ray that misses everything at once.  The traversal kernels walk a dead entry like any other; the next sort drops it.
-#define RT_SHADE_PER_THREAD 16u       // entries per thread and trip (measured: 4: 1988, 8: 2073, 16: 2098 Msamples/s)
+#ifndef RT_SHADE_PER_THREAD
+// entries per thread and trip.  Shading kernel per 10 rows of the final scene, three workgroups per CU (160 registers):
+// 4: 63.4 ms, 6: 59.3, 8: 59.0, 12: 59.9, 16: 63.8 (52 KB of LDS per workgroup leave the CU no room beside three of them)
+#define RT_SHADE_PER_THREAD 8u
+#endif
 #define RT_SHADE_CHUNK (256u * RT_SHADE_PER_THREAD)  // entries a workgroup sorts and shades per trip
 #define RT_SHADE_SLOTS (4u * RT_SHADE_PER_THREAD)    // (wave, pass) pairs of a trip
 #define RT_SHADE_KEYS 16u             // material class << 1 | sphere
