@@ -722,11 +722,13 @@ RT_HD bool walk_flat(const Scene& S, const uint64_t* prog, uint32_t begin, bool 
 #endif
   };
   uint64_t unit = header(i);
+  RT_PROF_START();
   for (;;) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)unit), idx = RTX_NODE_IDX((uint32_t)unit), count = (uint32_t)(unit >> 32);
     if (kind == PROG_NODE_END) break;
     if (skip_until != 0 && skip_until <= i) skip_until = 0;
     const bool on = active && skip_until == 0;
+    RT_PROF_LANES(RT_WAVE_COUNT(on));
     uint32_t next = kind == PROG_NODE_DEFER ? i + 1u : i + prog_record_units(unit);
     // the header of the unit behind this one is read while this one is computed (a box that nobody passes goes elsewhere)
     const uint64_t unit_behind = prog[next];
@@ -737,7 +739,7 @@ RT_HD bool walk_flat(const Scene& S, const uint64_t* prog, uint32_t begin, bool 
         pass = slab_hit((const double*)(prog + i + 1), lr, tmin, tmax);
         if (!pass) skip_until = count;
       }
-      if (!RT_WAVE_ANY(pass)) { next = count; unit = header(next); i = next; continue; }   // nobody goes in: every lane that was in waits at the skip target, the others beyond it
+      if (!RT_WAVE_ANY(pass)) { next = count; unit = header(next); i = next; RT_PROF_TRIP(6); continue; }   // nobody goes in: every lane that was in waits at the skip target, the others beyond it
     } else if (kind == PROG_NODE_SPHERE_S) {
       if (on) {
         for (uint32_t k = 0; k < count; ++k) {
@@ -830,6 +832,8 @@ RT_UNROLL
       if (on) deferred = true;
     }
     // (filler, SYNC, a medium this query ignores: nothing to do)
+    // (tuning build: slots of the per-ray walk's table that it does not use in a kernel that sweeps; 6 = boxes, transforms, rest)
+    RT_PROF_TRIP(kind == PROG_NODE_MEDIUM_S ? 5 : kind == PROG_NODE_SPHERE_S ? 1 : kind == RTX_NODE_SPHERE ? 3 : kind == PROG_NODE_QUAD_AA ? 2 : kind == RTX_NODE_QUAD ? 4 : kind == PROG_NODE_BOX6 ? 7 : 6);
     i = next;
 #if defined(__HIP_DEVICE_COMPILE__)
     unit = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unit_behind >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)unit_behind);

@@ -8,7 +8,7 @@ import sys
 path, segments = sys.argv[1], float(sys.argv[2])
 kernels, cur = {}, None
 for line in open(path):
-    m = re.match(r"^(\S.*?)\s+dispatches=(\d+)", line)
+    m = re.match(r"^(.*?)\s*dispatches=(\d+)", line)
     if m:
         cur = kernels.setdefault(m.group(1), {"dispatches": int(m.group(2))})
         continue

@@ -15,8 +15,11 @@ import torch  # noqa: E402
 import raytracing_rust_amd as rt  # noqa: E402
 from raytracing_rust_amd import _capi  # noqa: E402
 
-NAMES = {0: "cheap", 1: "SPHERE_S", 2: "QUAD_AA", 3: "SPHERE", 4: "QUAD", 5: "MEDIUM_EVAL", 6: "SYNC", 7: "BOX6",
+NAMES = {0: "cheap", 1: "SPHERE_S", 2: "QUAD_AA", 3: "SPHERE", 4: "QUAD", 5: "MEDIUM", 6: "SYNC / sweep: rest", 7: "BOX6",
          8: "box loop exit", 9: "box step"}
+# In a kernel that sweeps the flat stretch of the program (walk_flat), classes 1 to 5 and 7 are units of the sweep
+# (one trip = one unit for the whole wave), 6 its boxes, transforms and the rest; 0, 8, 9 (and 7 inside the head
+# section) belong to the per-ray walk of the new camera rays through the head section.
 
 
 def main():
