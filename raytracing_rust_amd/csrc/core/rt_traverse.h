@@ -148,6 +148,12 @@ RT_HD uint32_t prog_record_units(uint64_t unit) {
 // Wave-level votes.  On the GPU they steer the 64 lanes of a wave through the traversal loop together; in the host
 // build a "wave" is one ray and they reduce to the lane's own predicate.
 // Optional cycle accounting of the traversal loop (a tuning build defines RT_PROF_TRIP; the product does not).
+#ifndef RT_WPROF
+#define RT_WPROF_DECL() do { } while (0)
+#define RT_WPROF(slot, value) do { } while (0)
+#define RT_WPROF_CLOCK() 0ll
+#define RT_WPROF_FLUSH() do { } while (0)
+#endif
 #ifndef RT_PROF_TRIP
 #define RT_PROF_START() do { } while (0)
 #define RT_PROF_LANES(n) do { } while (0)
@@ -1550,6 +1556,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
     if (nq == 0) { qa_idx = idx; qa_pos = pos; } else { qb_idx = idx; qb_pos = pos; }
     nq += 1;
   };
+  RT_WPROF_DECL();
   for (;;) {
     if (have && st == ST_POP) {   // nothing left where the lane stood: the nearest box left behind, or hand in
       if (sp == 0) {
@@ -1602,8 +1609,13 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
       if (n_node < RT_WIDE_MIN_NODE && n_node < top) on_node = false;
       if (n_leaf < RT_WIDE_MIN_LEAF && n_leaf < top) on_leaf = false;
       if (n_quad < RT_WIDE_MIN_QUAD && n_quad < top) on_quad = false;
+      RT_WPROF(0, 1); RT_WPROF(1, RT_WAVE_COUNT(have)); RT_WPROF(2, n_node); RT_WPROF(3, n_leaf); RT_WPROF(4, n_quad);
+      RT_WPROF(5, RT_WAVE_ANY(on_node) ? 1 : 0); RT_WPROF(6, RT_WAVE_COUNT(on_node));
+      RT_WPROF(7, RT_WAVE_ANY(on_leaf) ? 1 : 0); RT_WPROF(8, RT_WAVE_COUNT(on_leaf));
+      RT_WPROF(9, RT_WAVE_ANY(on_quad) ? 1 : 0); RT_WPROF(10, RT_WAVE_COUNT(on_quad));
     }
 #endif
+    const long long wp_t0 = RT_WPROF_CLOCK(); (void)wp_t0;
     uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
 RT_UNROLL
     for (int k = 0; k < 16; ++k) blob[k] = 0ull;
@@ -1617,6 +1629,7 @@ RT_UNROLL
       for (int k = 0; k < 16; ++k) blob[k] = src[k];
       blob16 = src[16];
     }
+    const long long wp_t1 = RT_WPROF_CLOCK(); (void)wp_t1;
     if (RT_WAVE_ANY(on_node)) {
       if (on_node) {
         const float FINF = (float)RT_INF;
@@ -1657,6 +1670,7 @@ RT_UNROLL
       }
     }
     uint32_t rest_p = 0, rest_end = 0;
+    const long long wp_t2 = RT_WPROF_CLOCK(); (void)wp_t2;
     if (RT_WAVE_ANY(on_leaf)) {
       if (on_leaf) {
         double e;
@@ -1695,6 +1709,7 @@ RT_UNROLL
         } else st = ST_POP;
       }
     }
+    const long long wp_t3 = RT_WPROF_CLOCK(); (void)wp_t3;
     if (QUADS && RT_WAVE_ANY(on_quad)) {
       if (on_quad) {   // rtx_quad: q, u, v, normal, w (three units each), d
         double t;
@@ -1706,10 +1721,17 @@ RT_UNROLL
         RT_TRACE_STEP(32u + 4u);
       }
     }
+    const long long wp_t4 = RT_WPROF_CLOCK(); (void)wp_t4;
     if (RT_WAVE_ANY(rest_p < rest_end)) {   // records of a leaf that the read did not cover, or of another kind: from memory
+      RT_WPROF(11, 1);
       if (rest_p < rest_end) records(rest_p, rest_end, false);
     }
+    // (tuning build) cycles: issue of the reads, record step, leaf step, quad step, the rest; the whole trip is the sum
+    // of these and of the top of the next trip (pops, refill)
+    RT_WPROF(12, wp_t1 - wp_t0); RT_WPROF(13, wp_t2 - wp_t1); RT_WPROF(14, wp_t3 - wp_t2); RT_WPROF(15, wp_t4 - wp_t3); RT_WPROF(16, RT_WPROF_CLOCK() - wp_t4);
+    RT_WPROF(17, RT_WPROF_CLOCK() - wp_t0);
   }
+  RT_WPROF_FLUSH();
 }
 
 // What the integrator needs from a hit: the fields of HitRecord (hittable.rs:9-17) in world space.

@@ -18,6 +18,7 @@
 // in LDS; the traversal kernel flushes the block's sums to g_prof once, when it ends.
 __device__ unsigned long long g_prof[64];
 __device__ unsigned long long g_sprof[32];
+__device__ unsigned long long g_wprof[32];   // folded-table walk: trips, lanes waiting and served per kind of step, cycles
 __shared__ unsigned long long g_prof_lds[16 * 30];
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_PROF_START() long long prof_t0 = clock64(); int prof_lanes = 0; (void)prof_lanes
@@ -32,6 +33,15 @@ __shared__ unsigned long long g_prof_lds[16 * 30];
       p_[20 + (slot)] += (unsigned long long)prof_lanes;                         \
     }                                                                            \
     prof_t0 = clock64();                                                         \
+  } while (0)
+// folded-table walk (walk_stream_wide): sums per trip kept in registers, added up by lane 0 of every wave at the end
+#define RT_WPROF_DECL() unsigned long long wp_acc[18] = {0}
+#define RT_WPROF(slot, value) wp_acc[(slot)] += (unsigned long long)(value)
+#define RT_WPROF_CLOCK() clock64()
+#define RT_WPROF_FLUSH()                                                                              \
+  do {                                                                                                \
+    if ((threadIdx.x & 63u) == 0)                                                                     \
+      for (int k_ = 0; k_ < 18; ++k_) atomicAdd(&g_wprof[k_], wp_acc[k_]);                            \
   } while (0)
 // shading kernel: sections of shade_bounce, measured by the first active lane of the wave, one block in eight
 #define RT_SPROF_START() long long sprof_t0 = clock64()
@@ -1975,6 +1985,14 @@ extern "C" int rtx_debug_prof_read(unsigned long long* out64, int reset) {
   if (reset) {
     unsigned long long zero[64] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+extern "C" int rtx_debug_wprof_read(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wprof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wprof), zero, sizeof(zero)) != hipSuccess) return -1;
   }
   return 0;
 }
