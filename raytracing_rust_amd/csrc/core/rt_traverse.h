@@ -1391,6 +1391,16 @@ RT_HD bool slab_cull_entry_f(float lx, float ly, float lz, float hx, float hy, f
   entry = tmin;
   return !(tmax <= tmin);
 }
+// The same for a ray that skips no axis, without a branch: the entry, or +infinity when the ray misses the box.
+RT_HD float slab_entry_or_inf_f(float lx, float ly, float lz, float hx, float hy, float hz, float ix, float iy, float iz, float ox, float oy, float oz,
+                                float tmin, float tmax) {
+  const float ax = fmaf(lx, ix, -ox), bx = fmaf(hx, ix, -ox);
+  const float ay = fmaf(ly, iy, -oy), by = fmaf(hy, iy, -oy);
+  const float az = fmaf(lz, iz, -oz), bz = fmaf(hz, iz, -oz);
+  tmin = fmaxf(tmin, fmaxf(fminf(ax, bx), fmaxf(fminf(ay, by), fminf(az, bz))));
+  tmax = fminf(tmax, fminf(fmaxf(ax, bx), fminf(fmaxf(ay, by), fmaxf(az, bz))));
+  return tmax <= tmin ? (float)RT_INF : tmin;
+}
 RT_HD float unit_f32f(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return f; }
 RT_HD double unit_f64(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 RT_HD double unit_f32(uint64_t u, int high) { const uint32_t w = (uint32_t)(high ? u >> 32 : u); float f; memcpy(&f, &w, 4); return (double)f; }
@@ -1510,6 +1520,9 @@ RT_HD RT_NOINLINE WideBest wide_walk_records(const uint64_t* prog, const rtx_qua
 #ifndef RT_WIDE_MIN_QUAD
 #define RT_WIDE_MIN_QUAD RT_WIDE_MIN_LANES
 #endif
+#ifndef RT_WIDE_STRAIGHT
+#define RT_WIDE_STRAIGHT 1   // the record step as straight-line code (0: with a branch per slot and per push)
+#endif
 #ifndef RT_WIDE_REFILL
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WIDE_REFILL 16   // lanes out of work at which the wave takes new rays
@@ -1588,7 +1601,12 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         double root_entry = 0.0;
         const bool root = slab_hit_entry((const double*)(prog + begin + 1), lr, tmin, tmax_hi, root_entry);
         shift = (float)root_entry;
+#if RT_WIDE_STRAIGHT
+        // (a ray parallel to an axis too: the table's box test below has no case for skipped axes)
+        const bool far = lr.skip != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
+#else
         const bool far = (lr.skip & 8u) != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
+#endif
         suspect = root && far;
         node = 0; st = (root && !far) ? ST_NODE : ST_POP;
       }
@@ -1641,6 +1659,33 @@ RT_UNROLL
         const float ox = (float)(lr.o.x * lr.inv.x + sh), oy = (float)(lr.o.y * lr.inv.y + sh), oz = (float)(lr.o.z * lr.inv.z + sh);
         const float tlo = (float)(lo_t - fabs(lo_t) * 2e-7 - 1e-30), thi = (float)(hi_t + fabs(hi_t) * 2e-7 + 1e-30);
         const uint64_t d0 = blob[12], d1 = blob[13], d2 = blob[14], d3 = blob[15];
+#if RT_WIDE_STRAIGHT
+        // Straight-line code, selects instead of branches: the four tests, the sort, three stores to the stack of which
+        // a later one overwrites an earlier one that was not wanted (the stack pointer only moves past wanted entries;
+        // a level of the table owns three entries, so the stores stay inside the lane's stack), the next place.
+        e0 = slab_entry_or_inf_f(unit_f32f(blob[0], 0), unit_f32f(blob[0], 1), unit_f32f(blob[1], 0), unit_f32f(blob[1], 1), unit_f32f(blob[2], 0), unit_f32f(blob[2], 1), ix, iy, iz, ox, oy, oz, tlo, thi);
+        e1 = slab_entry_or_inf_f(unit_f32f(blob[3], 0), unit_f32f(blob[3], 1), unit_f32f(blob[4], 0), unit_f32f(blob[4], 1), unit_f32f(blob[5], 0), unit_f32f(blob[5], 1), ix, iy, iz, ox, oy, oz, tlo, thi);
+        e2 = slab_entry_or_inf_f(unit_f32f(blob[6], 0), unit_f32f(blob[6], 1), unit_f32f(blob[7], 0), unit_f32f(blob[7], 1), unit_f32f(blob[8], 0), unit_f32f(blob[8], 1), ix, iy, iz, ox, oy, oz, tlo, thi);
+        e3 = slab_entry_or_inf_f(unit_f32f(blob[9], 0), unit_f32f(blob[9], 1), unit_f32f(blob[10], 0), unit_f32f(blob[10], 1), unit_f32f(blob[11], 0), unit_f32f(blob[11], 1), ix, iy, iz, ox, oy, oz, tlo, thi);
+        e0 = d0 != PROG_WIDE_EMPTY ? e0 : FINF; e1 = d1 != PROG_WIDE_EMPTY ? e1 : FINF;
+        e2 = d2 != PROG_WIDE_EMPTY ? e2 : FINF; e3 = d3 != PROG_WIDE_EMPTY ? e3 : FINF;
+        // an entry of the stack, or the next place, from a slot's descriptor (a record of the table, or 0x80000000 | the
+        // unit position of a leaf)
+        auto word_of = [&](uint64_t dsc) { return (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc); };
+        uint32_t w0 = word_of(d0), w1 = word_of(d1), w2 = word_of(d2), w3 = word_of(d3);
+        // the slots by entry, nearest first (equal entries in no particular order: the closest hit does not depend on
+        // the order of the visits); a slot that failed sorts last
+#define RT_WIDE_CE(ea, wa, eb, wb) { const bool sw_ = ea > eb; const float te_ = sw_ ? eb : ea, tf_ = sw_ ? ea : eb; const uint32_t tw_ = sw_ ? wb : wa, tx_ = sw_ ? wa : wb; ea = te_; eb = tf_; wa = tw_; wb = tx_; }
+        RT_WIDE_CE(e0, w0, e1, w1) RT_WIDE_CE(e2, w2, e3, w3) RT_WIDE_CE(e0, w0, e2, w2) RT_WIDE_CE(e1, w1, e3, w3) RT_WIDE_CE(e1, w1, e2, w2)
+#undef RT_WIDE_CE
+        stk[sp * stk_stride] = w3; sp += e3 < FINF ? 1u : 0u;
+        stk[sp * stk_stride] = w2; sp += e2 < FINF ? 1u : 0u;
+        stk[sp * stk_stride] = w1; sp += e1 < FINF ? 1u : 0u;
+        const bool go = e0 < FINF, to_leaf = (w0 & 0x80000000u) != 0u;
+        node = go && !to_leaf ? w0 : node;
+        i = go && to_leaf ? (w0 & 0x7FFFFFFFu) : i;
+        st = go ? (to_leaf ? (uint32_t)ST_LEAF : (uint32_t)ST_NODE) : (uint32_t)ST_POP;
+#else
         if (!(d0 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[0], 0), unit_f32f(blob[0], 1), unit_f32f(blob[1], 0), unit_f32f(blob[1], 1), unit_f32f(blob[2], 0), unit_f32f(blob[2], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e0))) e0 = FINF;
         if (!(d1 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[3], 0), unit_f32f(blob[3], 1), unit_f32f(blob[4], 0), unit_f32f(blob[4], 1), unit_f32f(blob[5], 0), unit_f32f(blob[5], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e1))) e1 = FINF;
         if (!(d2 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[6], 0), unit_f32f(blob[6], 1), unit_f32f(blob[7], 0), unit_f32f(blob[7], 1), unit_f32f(blob[8], 0), unit_f32f(blob[8], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e2))) e2 = FINF;
@@ -1666,6 +1711,7 @@ RT_UNROLL
           if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
           else { i = (uint32_t)dsc; st = ST_LEAF; }
         } else st = ST_POP;
+#endif
         RT_TRACE_STEP(RTX_NODE_BOX);
       }
     }
@@ -1680,6 +1726,29 @@ RT_UNROLL
           uint32_t p = i;
           // the first two records from the registers where they are single static spheres, a pair of them, or
           // general quads (units 7.. of the read are the leaf's)
+#if RT_WIDE_STRAIGHT
+          // Which records these are is decided first and the operands of at most two sphere tests are selected, so that
+          // the wave runs the sphere test twice and not once per arrangement of the records (five of them).
+          const uint64_t u0 = blob[7];
+          const uint32_t k0 = RTX_NODE_KIND((uint32_t)u0), c0 = (uint32_t)(u0 >> 32), idx0 = RTX_NODE_IDX((uint32_t)u0);
+          const bool has0 = p < end;
+          const bool q0 = QUADS && has0 && k0 == RTX_NODE_QUAD;
+          const bool s1 = has0 && k0 == PROG_NODE_SPHERE_S && c0 == 1u, s2 = has0 && k0 == PROG_NODE_SPHERE_S && c0 == 2u;
+          const uint64_t u1 = q0 ? blob[8] : blob[12];                     // the record behind a quad / behind a single sphere
+          const uint32_t p1 = p + (q0 ? 1u : 1u + PROG_SPHERE_S_UNITS);
+          const uint32_t k1 = RTX_NODE_KIND((uint32_t)u1), c1 = (uint32_t)(u1 >> 32), idx1 = RTX_NODE_IDX((uint32_t)u1);
+          const bool has1 = (q0 || s1) && p1 < end;
+          const bool q1 = QUADS && has1 && k1 == RTX_NODE_QUAD, t1 = has1 && k1 == PROG_NODE_SPHERE_S && c1 == 1u;
+          if (q0) note_quad(idx0, (p << 6) + 1u);
+          if (q1) note_quad(idx1, (p1 << 6) + 1u);
+          const bool first = s1 || s2;                                      // sphere A: the first record's (first) sphere, or the one behind a quad
+          const bool va = first || (q0 && t1), vb = s2 || (s1 && t1);       // sphere B: the second of a pair, or the one behind a single sphere
+          const uint64_t ax = first ? blob[8] : blob[9], ay = first ? blob[9] : blob[10], az = first ? blob[10] : blob[11], ar = first ? blob[11] : blob[12];
+          const uint64_t bx = s2 ? blob[12] : blob[13], by = s2 ? blob[13] : blob[14], bz = s2 ? blob[14] : blob[15], br = s2 ? blob[15] : blob16;
+          if (va) sphere_v(ax, ay, az, ar, first ? idx0 : idx1, first ? (p << 6) + 1u : (p1 << 6) + 1u);
+          if (vb) sphere_v(bx, by, bz, br, s2 ? idx0 + 1u : idx1, s2 ? (p << 6) + 2u : (p1 << 6) + 1u);
+          p = s2 ? p + 1u + 2u * PROG_SPHERE_S_UNITS : ((q0 || s1) ? p1 + (q1 ? 1u : (t1 ? 1u + PROG_SPHERE_S_UNITS : 0u)) : p);
+#else
           const uint64_t u0 = blob[7];
           const uint32_t k0 = RTX_NODE_KIND((uint32_t)u0), c0 = (uint32_t)(u0 >> 32);
           if (p < end && QUADS && k0 == RTX_NODE_QUAD) {
@@ -1703,6 +1772,7 @@ RT_UNROLL
             sphere_v(blob[12], blob[13], blob[14], blob[15], RTX_NODE_IDX((uint32_t)u0) + 1u, (p << 6) + 2u);
             p += 1u + 2u * PROG_SPHERE_S_UNITS;
           }
+#endif
           rest_p = p; rest_end = end;       // whatever else the leaf holds: below, when the registers of the read are free
           st = nq ? ST_QUAD : ST_POP;
           RT_TRACE_STEP(32u + 1u);
