@@ -1571,6 +1571,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
   };
   RT_WPROF_DECL();
   for (;;) {
+    const long long wp_top = RT_WPROF_CLOCK(); (void)wp_top;
     if (have && st == ST_POP) {   // nothing left where the lane stood: the nearest box left behind, or hand in
       if (sp == 0) {
         if (suspect) {   // once more over the program, this lane alone, in the reference's order
@@ -1634,6 +1635,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
     }
 #endif
     const long long wp_t0 = RT_WPROF_CLOCK(); (void)wp_t0;
+    RT_WPROF(18, wp_t0 - wp_top);
     uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
 RT_UNROLL
     for (int k = 0; k < 16; ++k) blob[k] = 0ull;

@@ -35,13 +35,13 @@ __shared__ unsigned long long g_prof_lds[16 * 30];
     prof_t0 = clock64();                                                         \
   } while (0)
 // folded-table walk (walk_stream_wide): sums per trip kept in registers, added up by lane 0 of every wave at the end
-#define RT_WPROF_DECL() unsigned long long wp_acc[18] = {0}
+#define RT_WPROF_DECL() unsigned long long wp_acc[20] = {0}
 #define RT_WPROF(slot, value) wp_acc[(slot)] += (unsigned long long)(value)
 #define RT_WPROF_CLOCK() clock64()
 #define RT_WPROF_FLUSH()                                                                              \
   do {                                                                                                \
     if ((threadIdx.x & 63u) == 0)                                                                     \
-      for (int k_ = 0; k_ < 18; ++k_) atomicAdd(&g_wprof[k_], wp_acc[k_]);                            \
+      for (int k_ = 0; k_ < 20; ++k_) atomicAdd(&g_wprof[k_], wp_acc[k_]);                            \
   } while (0)
 // shading kernel: sections of shade_bounce, measured by the first active lane of the wave, one block in eight
 #define RT_SPROF_START() long long sprof_t0 = clock64()

@@ -45,10 +45,10 @@ def main():
     for name, t, n in (("record", 5, 6), ("leaf", 7, 8), ("quad", 9, 10)):
         print(f"{name:7s} step ran in {b[t] / trips:6.1%} of the trips with {b[n] / max(1, b[t]):5.1f} lanes")
     print(f"trips with records from memory: {b[11] / trips:.2%}")
-    tot = max(1, b[17])
-    for name, k in (("issue of the reads", 12), ("record step", 13), ("leaf step", 14), ("quad step", 15), ("records from memory", 16)):
+    tot = max(1, b[17] + b[18])
+    for name, k in (("pops, hand-in, refill", 18), ("issue of the reads", 12), ("record step", 13), ("leaf step", 14), ("quad step", 15), ("records from memory", 16)):
         print(f"{name:20s} {b[k] / tot:6.1%} of the trip cycles, {b[k] / trips:7.0f} cycles per trip")
-    print(f"cycles per trip (without pops and refill): {tot / trips:.0f}; lane steps per trip {(b[6] + b[8] + b[10]) / trips:.1f}")
+    print(f"cycles per trip: {tot / trips:.0f}; lane steps per trip {(b[6] + b[8] + b[10]) / trips:.1f}")
     scene.close()
     ctx.close()
 
