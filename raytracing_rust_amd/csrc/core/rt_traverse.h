@@ -1536,7 +1536,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
   const double tmin = 0.001;
   bool have = false, best_quad = false, suspect = false;
   double leaf_entry = -RT_INF, tmax_hi = RT_INF, tmax = RT_INF;
-  uint32_t id = 0, st = ST_POP, node = 0, i = begin, sp = 0, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
+  uint32_t id = 0, st = ST_POP, node = 0, i = begin, sp = 0 /* top of the lane's stack as an offset into stk: entries x stk_stride */, hit_kind = RTX_NODE_MAKE(RTX_NODE_NONE, 0), hit_ctx = 0, best_pos = 0;
   uint32_t nq = 0, qa_idx = 0, qa_pos = 0, qb_idx = 0, qb_pos = 0;   // quads of the current leaf still to test
   float shift = 0.0f;   // the table's tests measure ray parameters from here: where the ray enters the root box
   auto rs = feed.ray(0);
@@ -1583,8 +1583,8 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         }
         feed.commit(id, tmax, hit_kind, hit_ctx); have = false;
       } else {
-        sp -= 1;
-        const uint32_t e = stk[sp * stk_stride];
+        sp -= stk_stride;
+        const uint32_t e = stk[sp];
         if (e & 0x80000000u) { i = e & 0x7FFFFFFFu; st = ST_LEAF; }
         else { node = e; st = ST_NODE; }
       }
@@ -1637,8 +1637,15 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
     const long long wp_t0 = RT_WPROF_CLOCK(); (void)wp_t0;
     RT_WPROF(18, wp_t0 - wp_top);
     uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
+#if defined(__HIP_DEVICE_COMPILE__) && RT_WIDE_STRAIGHT
+    // a lane that reads nothing in this trip uses none of these: they only have to be DEFINED, which an empty asm
+    // statement with an output says without an instruction (zeroing them is 32 moves a trip, 7 % of the walk's issue)
+RT_UNROLL
+    for (int k = 0; k < 16; ++k) asm volatile("" : "=v"(blob[k]));
+#else
 RT_UNROLL
     for (int k = 0; k < 16; ++k) blob[k] = 0ull;
+#endif
     if (on_node || on_quad) {
       const UnitPair* src = on_node ? (const UnitPair*)(wide + (size_t)node * PROG_WIDE_UNITS) : (const UnitPair*)(S.quads + qa_idx);
 RT_UNROLL
@@ -1680,9 +1687,9 @@ RT_UNROLL
 #define RT_WIDE_CE(ea, wa, eb, wb) { const bool sw_ = ea > eb; const float te_ = sw_ ? eb : ea, tf_ = sw_ ? ea : eb; const uint32_t tw_ = sw_ ? wb : wa, tx_ = sw_ ? wa : wb; ea = te_; eb = tf_; wa = tw_; wb = tx_; }
         RT_WIDE_CE(e0, w0, e1, w1) RT_WIDE_CE(e2, w2, e3, w3) RT_WIDE_CE(e0, w0, e2, w2) RT_WIDE_CE(e1, w1, e3, w3) RT_WIDE_CE(e1, w1, e2, w2)
 #undef RT_WIDE_CE
-        stk[sp * stk_stride] = w3; sp += e3 < FINF ? 1u : 0u;
-        stk[sp * stk_stride] = w2; sp += e2 < FINF ? 1u : 0u;
-        stk[sp * stk_stride] = w1; sp += e1 < FINF ? 1u : 0u;
+        stk[sp] = w3; sp += e3 < FINF ? stk_stride : 0u;
+        stk[sp] = w2; sp += e2 < FINF ? stk_stride : 0u;
+        stk[sp] = w1; sp += e1 < FINF ? stk_stride : 0u;
         const bool go = e0 < FINF, to_leaf = (w0 & 0x80000000u) != 0u;
         node = go && !to_leaf ? w0 : node;
         i = go && to_leaf ? (w0 & 0x7FFFFFFFu) : i;
@@ -1702,8 +1709,8 @@ RT_UNROLL
         auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
         auto push = [&](uint32_t k) {
           const uint64_t dsc = desc_of(k);
-          stk[sp * stk_stride] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc);
-          sp += 1;
+          stk[sp] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc);
+          sp += stk_stride;
         };
         if (e3 < FINF) push(k3);
         if (e2 < FINF) push(k2);
