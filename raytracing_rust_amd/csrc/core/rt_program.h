@@ -209,8 +209,14 @@ struct CompiledProgram {
         if (k == RTX_NODE_MEDIUM) ok = false;
         if (k == RTX_NODE_BOX) ++boxes;
       }
-      main_flat = ok && boxes <= 16u;
       flat_begin = head_end ? head_end + 1u : world_begin;
+      // the part in front of it (the head section) is walked per ray by the same kernels, with walk_program<.., PLAIN>:
+      // it must hold no transform
+      for (uint32_t i = world_begin; i < flat_begin && ok; i += prog_record_units(units[i])) {
+        const uint32_t k = RTX_NODE_KIND((uint32_t)units[i]);
+        if (k == RTX_NODE_ENTER || k == RTX_NODE_EXIT || k == RTX_NODE_MEDIUM || k == PROG_NODE_MEDIUM_S || k == PROG_NODE_DEFER) ok = false;
+      }
+      main_flat = ok && boxes <= 16u;
     }
   }
   bool main_flat = false;

@@ -457,7 +457,9 @@ struct RayMem {       // structure-of-arrays queue: f[k*cap], k = 0..5
 // runs the section later (same ray, tmax0 = the t found so far), which is the same walk cut in two because the
 // section is the last thing the world program visits.
 enum { MEDIA_NONE = 0, MEDIA_SPHERES = 1, MEDIA_ALL = 2 };
-template <int MEDIA, bool DEFER, class RaySrc>
+// PLAIN: the caller vouches that the walk meets no ENTER or EXIT unit (CompiledProgram::main_flat says so for the head
+// section): the local ray then never changes, and the compiler need not carry it through the loop as a variable.
+template <int MEDIA, bool DEFER, bool PLAIN = false, class RaySrc>
 RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bool active, const RaySrc& rs, double tm,
                         double tmin0, double tmax0, Hit& best, bool use_media, const PathRng& rng, uint32_t bounce,
                         double* stale_uv, uint32_t kind0 = RTX_NODE_MAKE(RTX_NODE_NONE, 0), uint32_t ctx0 = 0,
@@ -514,7 +516,7 @@ RT_HD bool walk_program(const Scene& S, const uint64_t* prog, uint32_t begin, bo
           } else {                                                             // boundary missed: resume the world
             mode = 0; next = ret_i; tmin = tmin0; tmax = out_tmax; hit_kind = out_kind; hit_ctx = out_ctx;
           }
-        } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
+        } else if (!PLAIN && (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT)) {
           // in the world context the local ray IS the world ray: only a lane that stands in another context re-reads it
           const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();
           cur = idx;
@@ -729,9 +731,16 @@ RT_HD bool walk_flat(const Scene& S, const uint64_t* prog, uint32_t begin, bool 
   };
   uint64_t unit = header(i);
   RT_PROF_START();
+  // Two loops, so that the local ray (18 registers) is not a loop-carried value of the loop that visits the units: the
+  // inner one runs through the units of ONE transform context and leaves at an ENTER, an EXIT or the END; the outer one
+  // makes the next context's ray.  (As one loop, the compiler kept two copies of the whole walk state and moved one
+  // into the other twice per unit: 33 moves a unit, a seventh of the kernel's instructions.)
+  for (;;) {
+  bool more_contexts = false;
   for (;;) {
     const uint32_t kind = RTX_NODE_KIND((uint32_t)unit), idx = RTX_NODE_IDX((uint32_t)unit), count = (uint32_t)(unit >> 32);
     if (kind == PROG_NODE_END) break;
+    if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) { more_contexts = true; break; }
     if (skip_until != 0 && skip_until <= i) skip_until = 0;
     const bool on = active && skip_until == 0;
     RT_PROF_LANES(RT_WAVE_COUNT(on));
@@ -784,13 +793,6 @@ RT_UNROLL
         double t;
         if (sphere_rec_hit_t((const double*)(prog + i + 1), lr.o, lr.d, tm, tmin, tmax, t)) { tmax = t; hit_kind = RTX_NODE_MAKE(RTX_NODE_SPHERE, idx); hit_ctx = cur; }
         RT_TRACE_STEP(32u + 3u);
-      }
-    } else if (kind == RTX_NODE_ENTER || kind == RTX_NODE_EXIT) {
-      if (on) {
-        const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();   // as in walk_program
-        cur = idx;
-        lr = lray_from_ops(prog + i + 1, count, wo, wd);
-        RT_TRACE_STEP(kind);
       }
     } else if (MEDIA != MEDIA_NONE && kind == PROG_NODE_MEDIUM_S && use_media) {
       if (on) {   // constant_medium.rs:42-90 for a boundary of one static sphere: as the MEDIUM_S step of walk_program
@@ -846,6 +848,23 @@ RT_UNROLL
 #else
     unit = unit_behind;
 #endif
+  }
+  if (!more_contexts) break;
+  {   // ENTER / EXIT: the ray of the context that begins here (for the lanes that are in)
+    const uint32_t idx = RTX_NODE_IDX((uint32_t)unit), count = (uint32_t)(unit >> 32);
+    if (skip_until != 0 && skip_until <= i) skip_until = 0;
+    const bool on = active && skip_until == 0;
+    RT_PROF_LANES(RT_WAVE_COUNT(on));
+    if (on) {
+      const V3 wo = cur == 0 ? lr.o : rs.origin(), wd = cur == 0 ? lr.d : rs.dir();   // as in walk_program
+      cur = idx;
+      lr = lray_from_ops(prog + i + 1, count, wo, wd);
+      RT_TRACE_STEP(RTX_NODE_KIND((uint32_t)unit));
+    }
+    RT_PROF_TRIP(6);
+    i += prog_record_units(unit);
+    unit = header(i);
+  }
   }
   best.t = tmax; best.kind_idx = hit_kind; best.ctx = hit_ctx;
   return deferred;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_traverse(Scene S, uint32
           const bool fresh = active && !behind;
           if (RT_WAVE_ANY(fresh)) {
             Hit hh;
-            walk_program<MEDIA_NONE, true>(S, prog, S.world_begin, fresh, rs, tm, 0.001, RT_INF, hh, false, rng, bounce, nullptr,
+            walk_program<MEDIA_NONE, true, true>(S, prog, S.world_begin, fresh, rs, tm, 0.001, RT_INF, hh, false, rng, bounce, nullptr,
                                            (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, gen, nray.o, nray.d, S.flat_begin - 1u);
             if (fresh) { t1 = hh.t; kind1 = hh.kind_idx; ctx1 = hh.ctx; }
           }
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
       Hit hh;
       hh.t = RT_INF; hh.kind_idx = (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0); hh.ctx = 0u;
       if (S.flat_begin != S.world_begin)
-        walk_program<MEDIA_NONE, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hh, false, ps.rng, ps.bounce, nullptr,
+        walk_program<MEDIA_NONE, true, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hh, false, ps.rng, ps.bounce, nullptr,
                                        (uint32_t)RTX_NODE_MAKE(RTX_NODE_NONE, 0), 0u, false, V3(), V3(), S.flat_begin - 1u);
       deferred = walk_flat<MM>(S, lds_prog, S.flat_begin, alive, rs, ray.tm, 0.001, hh.t, hit, MM != MEDIA_NONE,
                                ps.rng, ps.bounce, stale_uv, hh.kind_idx, hh.ctx, false, V3(), V3());

@@ -323,7 +323,7 @@ long sim_check_flat_walk(const rtx_scene_desc* desc, const double* rays, size_t 
     double uva[2] = {0.0, 0.0}, uvb[2] = {0.0, 0.0};
     closest_hit<true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, a, true, rng, bounce, uva);
     hh.t = RT_INF; hh.kind_idx = none; hh.ctx = 0;
-    if (S.flat_begin != S.world_begin) walk_program<MEDIA_NONE, true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, hh, false, rng, bounce, nullptr, none, 0u, false, V3(), V3(), S.flat_begin - 1u);
+    if (S.flat_begin != S.world_begin) walk_program<MEDIA_NONE, true, true>(S, S.prog, S.world_begin, true, rs, r[6], 0.001, RT_INF, hh, false, rng, bounce, nullptr, none, 0u, false, V3(), V3(), S.flat_begin - 1u);
     const bool deferred = walk_flat<MEDIA_SPHERES>(S, S.prog, S.flat_begin, true, rs, r[6], 0.001, hh.t, b, true, rng, bounce, uvb,
                                                    hh.kind_idx, hh.ctx, false, V3(), V3());
     if (deferred && S.tail_begin) {
