@@ -52,10 +52,10 @@ OWN_TRAVERSE_BYTES, OWN_NEW_PATH_BYTES, OWN_BOUNCE_BYTES = 100, 108, 390
 # active per VALU instruction.
 PMC = {
     "profile": "profiles/r3_pmc_summary.txt (one step of 10 rows, 1.06993e9 segments, one pipeline; tools/pmc_derive.py)",
-    "valu_wave_instructions_per_segment": 72.7,
-    # (2 x FETCH_SIZE + WRITE_SIZE) / segments; FETCH_SIZE as reported would give 80.7, 190.1, 40.9 and 9.9
-    "traffic_bytes_per_segment": {"k_wf_traverse": 106.4, "k_wf_shade": 314.0, "k_wf_stream_head": 58.0, "k_wf_stream_deferred": 15.8},
-    "lanes_active": {"k_wf_traverse": 58.0, "k_wf_stream_head": 42.2, "k_wf_stream_deferred": 34.8, "k_wf_shade": 41.0},
+    "valu_wave_instructions_per_segment": 69.8,
+    # (2 x FETCH_SIZE + WRITE_SIZE) / segments; FETCH_SIZE as reported would give 79.4, 190.1, 40.9 and 9.9
+    "traffic_bytes_per_segment": {"k_wf_traverse": 103.8, "k_wf_shade": 314.0, "k_wf_stream_head": 58.0, "k_wf_stream_deferred": 15.8},
+    "lanes_active": {"k_wf_traverse": 57.0, "k_wf_stream_head": 42.2, "k_wf_stream_deferred": 34.8, "k_wf_shade": 41.0},
 }
 SIMDS, CLOCK_GHZ, F64_CYCLES_PER_WAVE_INSTRUCTION = 256 * 4, 2.4, 4   # vector f64: 16 lanes per clock per SIMD
 

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(RT_TRAV_THREADS) void k_wf_stream(Scene S, uint32_t
 //
 // Sorting.  The branches of shade_bounce differ a lot in cost (a miss or a light ends the path at once, a marble hit
 // evaluates seven octaves of noise), and a wave pays for every branch one of its lanes takes.  A workgroup therefore
-// takes RT_SHADE_CHUNK (4096) queue entries at a time and first sorts them by a key made of the hit material's class
+// takes RT_SHADE_CHUNK (2048) queue entries at a time and first sorts them by a key made of the hit material's class
 // (rtx_scene::mat_class) and the kind of primitive: a stable counting sort in LDS, ballots within each wave and a
 // small prefix over (key, wave).  Waves then shade runs of equal keys.  Paths are addressed by their own
 // coordinates (RNG included), so the order in which they are shaded changes no result.
