@@ -331,7 +331,7 @@ struct CompiledProgram {
   // Whether a leaf's units are tested is decided by the program's own box record in front of them.
   // The bounds are padded by PROG_WIDE_PAD times the largest coordinate of the section's root box before they are
   // rounded outward: the walk tests them in single precision with one fused multiply-add per plane, measuring ray
-  // parameters from where the ray enters the root box (slab_cull_entry_f), and its results differ from Aabb::hit's by
+  // parameters from where the ray enters the root box (slab_entry_or_inf_f), and its results differ from Aabb::hit's by
   // at most 2.4e-7 of that largest coordinate in space units, an eighth of the pad, for ray origins within
   // head_wide_far = PROG_WIDE_FAR times it (beyond that the shift of the origin itself loses digits).
   static float round_down(double v) { float f = (float)v; return (double)f >= v ? nextafterf(f, -INFINITY) : f; }

@@ -1370,47 +1370,15 @@ RT_HD bool slab_hit_entry_v(double lx, double ly, double lz, double hx, double h
   entry = tmin;
   return !(tmax <= tmin);
 }
-// A padded box of the folded table against a ray: the slab test with one fused multiply-add per plane (oi = o * inv).
-// Only for culling: see CompiledProgram::build_head_wide for why it never fails a box that Aabb::hit passes.
-RT_HD bool slab_cull_entry(double lx, double ly, double lz, double hx, double hy, double hz, const LRay& r, const V3& oi, double tmin, double tmax, double& entry) {
-  const double ax = fma(lx, r.inv.x, -oi.x), bx = fma(hx, r.inv.x, -oi.x);
-  const double ay = fma(ly, r.inv.y, -oi.y), by = fma(hy, r.inv.y, -oi.y);
-  const double az = fma(lz, r.inv.z, -oi.z), bz = fma(hz, r.inv.z, -oi.z);
-  double nrx = rt_min(ax, bx), frx = rt_max(ax, bx), nry = rt_min(ay, by), fry = rt_max(ay, by), nrz = rt_min(az, bz), frz = rt_max(az, bz);
-  if (r.skip & 7u) {
-    if (r.skip & 1u) { nrx = -RT_INF; frx = RT_INF; }
-    if (r.skip & 2u) { nry = -RT_INF; fry = RT_INF; }
-    if (r.skip & 4u) { nrz = -RT_INF; frz = RT_INF; }
-  }
-  tmin = rt_max(tmin, nrx); tmax = rt_min(tmax, frx);
-  tmin = rt_max(tmin, nry); tmax = rt_min(tmax, fry);
-  tmin = rt_max(tmin, nrz); tmax = rt_min(tmax, frz);
-  entry = tmin;
-  return !(tmax <= tmin);
-}
-// The same in single precision, on the table's floats as they are: near and far plane distances by one fused
-// multiply-add each from inv and oi = o * inv rounded to float.  Their error is at most (|bound| + |origin|) |inv| 1.2e-7.
+// A padded box of the folded table against a ray, in single precision on the table's floats as they are: near and far
+// plane distances by one fused multiply-add each from inv and oi = o * inv rounded to float.  Only for culling: see
+// CompiledProgram::build_head_wide for why it never fails a box that Aabb::hit passes.  Their error is at most (|bound| + |origin|) |inv| 1.2e-7.
 // The caller measures ray parameters from where the ray enters the section's root box (oi = o * inv + shift is the
 // same ray with its origin moved there: d * inv = 1 on every axis that counts), so |origin| is within the section's
 // extent whatever the ray's own origin, and the table's pad (PROG_WIDE_PAD of the extent) exceeds the error eight
 // times over; tmin and tmax, measured from the same point, must be rounded outward by the caller.
-RT_HD bool slab_cull_entry_f(float lx, float ly, float lz, float hx, float hy, float hz, float ix, float iy, float iz, float ox, float oy, float oz,
-                             uint32_t skip, float tmin, float tmax, float& entry) {
-  const float ax = fmaf(lx, ix, -ox), bx = fmaf(hx, ix, -ox);
-  const float ay = fmaf(ly, iy, -oy), by = fmaf(hy, iy, -oy);
-  const float az = fmaf(lz, iz, -oz), bz = fmaf(hz, iz, -oz);
-  float nrx = fminf(ax, bx), frx = fmaxf(ax, bx), nry = fminf(ay, by), fry = fmaxf(ay, by), nrz = fminf(az, bz), frz = fmaxf(az, bz);
-  if (skip & 7u) {
-    if (skip & 1u) { nrx = -(float)RT_INF; frx = (float)RT_INF; }
-    if (skip & 2u) { nry = -(float)RT_INF; fry = (float)RT_INF; }
-    if (skip & 4u) { nrz = -(float)RT_INF; frz = (float)RT_INF; }
-  }
-  tmin = fmaxf(tmin, fmaxf(nrx, fmaxf(nry, nrz)));
-  tmax = fminf(tmax, fminf(frx, fminf(fry, frz)));
-  entry = tmin;
-  return !(tmax <= tmin);
-}
-// The same for a ray that skips no axis, without a branch: the entry, or +infinity when the ray misses the box.
+// For a ray that skips no axis (the caller sends the others the program's way), without a branch: the entry, or
+// +infinity when the ray misses the box.
 RT_HD float slab_entry_or_inf_f(float lx, float ly, float lz, float hx, float hy, float hz, float ix, float iy, float iz, float ox, float oy, float oz,
                                 float tmin, float tmax) {
   const float ax = fmaf(lx, ix, -ox), bx = fmaf(hx, ix, -ox);
@@ -1539,9 +1507,6 @@ RT_HD RT_NOINLINE WideBest wide_walk_records(const uint64_t* prog, const rtx_qua
 #ifndef RT_WIDE_MIN_QUAD
 #define RT_WIDE_MIN_QUAD RT_WIDE_MIN_LANES
 #endif
-#ifndef RT_WIDE_STRAIGHT
-#define RT_WIDE_STRAIGHT 1   // the record step as straight-line code (0: with a branch per slot and per push)
-#endif
 #ifndef RT_WIDE_REFILL
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RT_WIDE_REFILL 16   // lanes out of work at which the wave takes new rays
@@ -1621,12 +1586,8 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
         double root_entry = 0.0;
         const bool root = slab_hit_entry((const double*)(prog + begin + 1), lr, tmin, tmax_hi, root_entry);
         shift = (float)root_entry;
-#if RT_WIDE_STRAIGHT
         // (a ray parallel to an axis too: the table's box test below has no case for skipped axes)
         const bool far = lr.skip != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
-#else
-        const bool far = (lr.skip & 8u) != 0u || !(fabs(lr.o.x) <= S.head_wide_far && fabs(lr.o.y) <= S.head_wide_far && fabs(lr.o.z) <= S.head_wide_far);
-#endif
         suspect = root && far;
         node = 0; st = (root && !far) ? ST_NODE : ST_POP;
       }
@@ -1656,7 +1617,7 @@ RT_HD void walk_stream_wide(const Scene& S, const uint64_t* prog, uint32_t begin
     const long long wp_t0 = RT_WPROF_CLOCK(); (void)wp_t0;
     RT_WPROF(18, wp_t0 - wp_top);
     uint64_t blob[16], blob16 = 0ull;   // blob16: the 17th unit of a leaf's read (two single spheres need it)
-#if defined(__HIP_DEVICE_COMPILE__) && RT_WIDE_STRAIGHT
+#if defined(__HIP_DEVICE_COMPILE__)
     // a lane that reads nothing in this trip uses none of these: they only have to be DEFINED, which an empty asm
     // statement with an output says without an instruction (zeroing them is 32 moves a trip, 7 % of the walk's issue)
 RT_UNROLL
@@ -1687,7 +1648,6 @@ RT_UNROLL
         const float ox = (float)(lr.o.x * lr.inv.x + sh), oy = (float)(lr.o.y * lr.inv.y + sh), oz = (float)(lr.o.z * lr.inv.z + sh);
         const float tlo = (float)(lo_t - fabs(lo_t) * 2e-7 - 1e-30), thi = (float)(hi_t + fabs(hi_t) * 2e-7 + 1e-30);
         const uint64_t d0 = blob[12], d1 = blob[13], d2 = blob[14], d3 = blob[15];
-#if RT_WIDE_STRAIGHT
         // Straight-line code, selects instead of branches: the four tests, the sort, three stores to the stack of which
         // a later one overwrites an earlier one that was not wanted (the stack pointer only moves past wanted entries;
         // a level of the table owns three entries, so the stores stay inside the lane's stack), the next place.
@@ -1713,33 +1673,6 @@ RT_UNROLL
         node = go && !to_leaf ? w0 : node;
         i = go && to_leaf ? (w0 & 0x7FFFFFFFu) : i;
         st = go ? (to_leaf ? (uint32_t)ST_LEAF : (uint32_t)ST_NODE) : (uint32_t)ST_POP;
-#else
-        if (!(d0 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[0], 0), unit_f32f(blob[0], 1), unit_f32f(blob[1], 0), unit_f32f(blob[1], 1), unit_f32f(blob[2], 0), unit_f32f(blob[2], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e0))) e0 = FINF;
-        if (!(d1 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[3], 0), unit_f32f(blob[3], 1), unit_f32f(blob[4], 0), unit_f32f(blob[4], 1), unit_f32f(blob[5], 0), unit_f32f(blob[5], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e1))) e1 = FINF;
-        if (!(d2 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[6], 0), unit_f32f(blob[6], 1), unit_f32f(blob[7], 0), unit_f32f(blob[7], 1), unit_f32f(blob[8], 0), unit_f32f(blob[8], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e2))) e2 = FINF;
-        if (!(d3 != PROG_WIDE_EMPTY && slab_cull_entry_f(unit_f32f(blob[9], 0), unit_f32f(blob[9], 1), unit_f32f(blob[10], 0), unit_f32f(blob[10], 1), unit_f32f(blob[11], 0), unit_f32f(blob[11], 1), ix, iy, iz, ox, oy, oz, lr.skip, tlo, thi, e3))) e3 = FINF;
-        // the slots by entry, nearest first (equal entries: the program's order); a slot that failed sorts last
-        // (an entry is finite: the lower bound it starts from is).  Only the nearest in front and the others in the
-        // program's order measured the same: 165 against 167 Msamples/s on the stress scene.
-        uint32_t k0 = 0, k1 = 1, k2 = 2, k3 = 3;
-#define RT_WIDE_CE(ea, ka, eb, kb) { if (ea > eb || (ea == eb && ka > kb)) { const float te = ea; ea = eb; eb = te; const uint32_t tk = ka; ka = kb; kb = tk; } }
-        RT_WIDE_CE(e0, k0, e1, k1) RT_WIDE_CE(e2, k2, e3, k3) RT_WIDE_CE(e0, k0, e2, k2) RT_WIDE_CE(e1, k1, e3, k3) RT_WIDE_CE(e1, k1, e2, k2)
-#undef RT_WIDE_CE
-        auto desc_of = [&](uint32_t k) { return k == 0 ? d0 : k == 1 ? d1 : k == 2 ? d2 : d3; };
-        auto push = [&](uint32_t k) {
-          const uint64_t dsc = desc_of(k);
-          stk[sp] = (dsc >> 32) == 0ull ? (uint32_t)dsc : (0x80000000u | (uint32_t)dsc);
-          sp += stk_stride;
-        };
-        if (e3 < FINF) push(k3);
-        if (e2 < FINF) push(k2);
-        if (e1 < FINF) push(k1);
-        if (e0 < FINF) {
-          const uint64_t dsc = desc_of(k0);
-          if ((dsc >> 32) == 0ull) { node = (uint32_t)dsc; st = ST_NODE; }
-          else { i = (uint32_t)dsc; st = ST_LEAF; }
-        } else st = ST_POP;
-#endif
         RT_TRACE_STEP(RTX_NODE_BOX);
       }
     }
@@ -1754,7 +1687,6 @@ RT_UNROLL
           uint32_t p = i;
           // the first two records from the registers where they are single static spheres, a pair of them, or
           // general quads (units 7.. of the read are the leaf's)
-#if RT_WIDE_STRAIGHT
           // Which records these are is decided first and the operands of at most two sphere tests are selected, so that
           // the wave runs the sphere test twice and not once per arrangement of the records (five of them).
           const uint64_t u0 = blob[7];
@@ -1776,31 +1708,6 @@ RT_UNROLL
           if (va) sphere_v(ax, ay, az, ar, first ? idx0 : idx1, first ? (p << 6) + 1u : (p1 << 6) + 1u);
           if (vb) sphere_v(bx, by, bz, br, s2 ? idx0 + 1u : idx1, s2 ? (p << 6) + 2u : (p1 << 6) + 1u);
           p = s2 ? p + 1u + 2u * PROG_SPHERE_S_UNITS : ((q0 || s1) ? p1 + (q1 ? 1u : (t1 ? 1u + PROG_SPHERE_S_UNITS : 0u)) : p);
-#else
-          const uint64_t u0 = blob[7];
-          const uint32_t k0 = RTX_NODE_KIND((uint32_t)u0), c0 = (uint32_t)(u0 >> 32);
-          if (p < end && QUADS && k0 == RTX_NODE_QUAD) {
-            note_quad(RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u); p += 1u;
-            const uint64_t u1 = blob[8];
-            const uint32_t k1 = RTX_NODE_KIND((uint32_t)u1);
-            if (p < end && k1 == RTX_NODE_QUAD) { note_quad(RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u; }
-            else if (p < end && k1 == PROG_NODE_SPHERE_S && (uint32_t)(u1 >> 32) == 1u) {
-              sphere_v(blob[9], blob[10], blob[11], blob[12], RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
-            }
-          } else if (p < end && k0 == PROG_NODE_SPHERE_S && c0 == 1u) {
-            sphere_v(blob[8], blob[9], blob[10], blob[11], RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
-            const uint64_t u1 = blob[12];
-            const uint32_t k1 = RTX_NODE_KIND((uint32_t)u1);
-            if (p < end && QUADS && k1 == RTX_NODE_QUAD) { note_quad(RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u; }
-            else if (p < end && k1 == PROG_NODE_SPHERE_S && (uint32_t)(u1 >> 32) == 1u) {
-              sphere_v(blob[13], blob[14], blob[15], blob16, RTX_NODE_IDX((uint32_t)u1), (p << 6) + 1u); p += 1u + PROG_SPHERE_S_UNITS;
-            }
-          } else if (p < end && k0 == PROG_NODE_SPHERE_S && c0 == 2u) {
-            sphere_v(blob[8], blob[9], blob[10], blob[11], RTX_NODE_IDX((uint32_t)u0), (p << 6) + 1u);
-            sphere_v(blob[12], blob[13], blob[14], blob[15], RTX_NODE_IDX((uint32_t)u0) + 1u, (p << 6) + 2u);
-            p += 1u + 2u * PROG_SPHERE_S_UNITS;
-          }
-#endif
           rest_p = p; rest_end = end;       // whatever else the leaf holds: below, when the registers of the read are free
           st = nq ? ST_QUAD : ST_POP;
           RT_TRACE_STEP(32u + 1u);
