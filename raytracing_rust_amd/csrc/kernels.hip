@@ -792,11 +792,13 @@ __global__ __launch_bounds__(256) void k_wf_finish(Scene S, rtx_camera_desc cam,
   if (blockIdx.x == 0 && threadIdx.x == 0) c->finished = 1u;  // the next k_wf_prepare drops the survivors
 }
 
-// The same tail of a call for a program whose world program and deferred section each fit LDS: a workgroup keeps its
-// survivors (one per thread) to their end and walks every bounce from LDS, the world program staged first (a ray that passes the
-// deferred section's root box is noted, as in the wavefront traversal) and the deferred section's program after it for
-// the rays noted - the walk of world.hit cut in two, bit for bit.  From global memory a step of the walk costs a round
-// trip to the L2 (k_wf_finish: 220 us per bounce on the final scene); from LDS a third of that.
+// The same tail of a call for a program whose world program fits LDS: a workgroup keeps its survivors (one per thread,
+// refilled from the queue) to their end and walks every bounce of the world program from LDS, staged once; a ray that
+// passes the deferred section's root box is noted, as in the wavefront traversal, and walks that section where it lies,
+// in global memory - the walk of world.hit cut in two, bit for bit.  Nothing in the loop synchronises the waves of a
+// workgroup: each takes its bounces at its own pace.  (Staging the two parts in turn, with the barriers that needs,
+// made every bounce wait three times for the slowest of twelve waves: `quick` 1300 against 1340 Msamples/s; with the
+// deferred section walked nearer child first by the stream walker the kernel grew and lost that again: 1325.)
 #ifndef RT_FINISH_THREADS
 #define RT_FINISH_THREADS 768   // (one workgroup per CU for its LDS: 512: quick 1095, 768: 1135, 1024: 1125 Msamples/s - the registers of shading spill, but more paths finish per round)
 #endif
@@ -843,6 +845,15 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
   }
   uint32_t segs = 0, probes = 0;
   const uint32_t main_units = S.tail_begin ? S.tail_begin : S.n_units, tail_units = S.tail_begin ? S.n_units - S.tail_begin : 0u;   // both even
+  // The world program is staged ONCE and stays; the deferred section is walked where it lies, in global memory (the
+  // L2), by the rays that passed its root box.  No barrier follows in the loop: every wave takes its bounces at its own
+  // pace instead of waiting three times per bounce for the slowest of the workgroup's waves.
+  {
+    const uint4* src = (const uint4*)S.prog;
+    uint4* dst = (uint4*)lds_prog;
+    for (uint32_t k = threadIdx.x; k < main_units / 2; k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
   for (;;) {
     if (more) {   // lanes without a path take the next survivors
       const unsigned long long want = __ballot(!alive);
@@ -856,19 +867,10 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
         if (base + cnt >= n) more = false;
       }
     }
-    // (the barriers also keep the staged image until every wave is through with it)
-    const int any_alive = __syncthreads_or(alive ? 1 : 0);
-    const int any_more = __syncthreads_or(more ? 1 : 0);
-    if (!any_alive) {
-      if (any_more) continue;   // everything taken so far was a dead entry: take again
+    if (!__any(alive)) {
+      if (more) continue;       // everything taken so far was a dead entry: take again
       break;
     }
-    {
-      const uint4* src = (const uint4*)S.prog;
-      uint4* dst = (uint4*)lds_prog;
-      for (uint32_t k = threadIdx.x; k < main_units / 2; k += blockDim.x) dst[k] = src[k];
-    }
-    __syncthreads();
     Hit hit;
     double stale_uv[2] = {0.0, 0.0};
     if (alive) ++segs;
@@ -887,15 +889,12 @@ __global__ __launch_bounds__(RT_FINISH_THREADS) void k_wf_finish_lds(Scene S, rt
       deferred = walk_program<MM, true>(S, lds_prog, S.world_begin, alive, rs, ray.tm, 0.001, RT_INF, hit, MM != MEDIA_NONE, ps.rng, ps.bounce, stale_uv);
     }
     if (tail_units) {
-      __syncthreads();
-      const uint4* src = (const uint4*)(S.prog + S.tail_begin);
-      uint4* dst = (uint4*)lds_prog;
-      for (uint32_t k = threadIdx.x; k < tail_units / 2; k += blockDim.x) dst[k] = src[k];
-      __syncthreads();
       const bool in_section = alive && deferred;
-      Hit h2;
-      walk_program<MEDIA_NONE, false>(S, lds_prog - S.tail_begin, S.tail_begin, in_section, rs, ray.tm, 0.001, hit.t, h2, false, ps.rng, ps.bounce, stale_uv);
-      if (in_section && hit_any(h2)) hit = h2;
+      if (__any(in_section)) {
+        Hit h2;
+        walk_program<MEDIA_NONE, false>(S, S.prog, S.tail_begin, in_section, rs, ray.tm, 0.001, hit.t, h2, false, ps.rng, ps.bounce, stale_uv);
+        if (in_section && hit_any(h2)) hit = h2;
+      }
     }
     if (alive) {
       Ray next;
@@ -1411,10 +1410,10 @@ static WfPlan wf_make_plan(const rtx_scene* sc, uint32_t cap, unsigned long long
   {
     const size_t whole_main = (size_t)(tail_begin ? tail_begin : n_units) * 8;
     const char* fe = getenv("RTX_WF_FINISH_LDS");   // 0: the finishing kernel walks the program in global memory
-    if (whole_main <= kFinishLdsBudget && P.tail_bytes <= kFinishLdsBudget && !(fe && atoi(fe) == 0)) {
+    if (whole_main <= kFinishLdsBudget && !(fe && atoi(fe) == 0)) {   // (the deferred section is walked where it lies)
       P.k_finish_lds = mm == MEDIA_NONE ? k_wf_finish_lds<MEDIA_NONE> : mm == MEDIA_SPHERES ? k_wf_finish_lds<MEDIA_SPHERES> : k_wf_finish_lds<MEDIA_ALL>;
       if (sc->dev.main_flat != 0 && mm != MEDIA_ALL) P.k_finish_lds = mm == MEDIA_NONE ? k_wf_finish_lds<MEDIA_NONE, true> : k_wf_finish_lds<MEDIA_SPHERES, true>;
-      P.finish_lds_bytes = std::max(whole_main, P.tail_bytes);
+      P.finish_lds_bytes = whole_main;
     }
   }
   P.finish_at = finish_threshold(sc->dev.head_end != 0 && !P.head_lds);
