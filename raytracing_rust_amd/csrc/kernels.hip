@@ -1497,10 +1497,10 @@ static rtx_status render_wavefront(rtx_scene* sc, const rtx_camera_desc* cam, co
   const unsigned long long per_sample = (unsigned long long)(o->x1 - o->x0) * (unsigned long long)(o->y1 - o->y0);
   const unsigned long long call_paths = per_sample * (unsigned long long)std::max(n_samples, 0);
   const char* lanes_env = getenv("RTX_WF_LANES");
-  // (a head section walked from global memory keeps every SIMD busy by itself: one pipeline, stress scene 167 against
-  // 159 Msamples/s with four)
+  // (a head section walked from global memory keeps most SIMDs busy by itself: two pipelines at most; stress scene with
+  // 1 / 2 / 3 / 4 pipelines: 241 / 245 / 234 / 235 Msamples/s)
   const bool head_in_global = sc->dev.head_end != 0 && (size_t)((sc->dev.head_end + 2u) & ~1u) * 8 > kLdsBudget;
-  const int want_lanes = lanes_env ? atoi(lanes_env) : head_in_global ? 1 : (int)std::min<unsigned long long>(4ull, (call_paths + (1ull << 22) - 1ull) >> 22);
+  const int want_lanes = lanes_env ? atoi(lanes_env) : (int)std::min<unsigned long long>(head_in_global ? 2ull : 4ull, (call_paths + (1ull << 22) - 1ull) >> 22);
   const int n_lanes = std::max(1, std::min(std::min(want_lanes, n_samples), RT_WF_MAX_LANES));
   uint32_t cap = 1u << 26;
   if (const char* e = getenv("RTX_WF_CAPACITY")) { long v = atol(e); if (v >= 1024 && v <= (1l << 27)) cap = (uint32_t)v; }
