@@ -135,8 +135,16 @@ def test_folded_table_walk_hands_rays_back_to_the_program_order():
     for k, o in enumerate([(3e8, 1e8, -2e8), (-4e13, 10.0, 20.0), (0.0, 6e8, 0.0), (2e6, -3e6, 1e6)]):
         rays[6 + k, 0:3] = o
         rays[6 + k, 3:6] = np.array([30.0 * k, -20.0, 10.0]) - np.array(o)
+    # rays parallel to an axis (a component of the direction below 1e-8 in magnitude: Aabb::hit skips that axis,
+    # aabb.rs:142-144) go the program's way as well: the table's box test has no case for skipped axes
     d = rt.flatten(gp, wp, lp)
+    for k, dvec in enumerate([(1.0, 0.0, 0.0), (0.0, -1.0, 0.0), (0.0, 0.0, 1.0), (0.3, 1e-9, -0.8)]):
+        centre = np.array(d.spheres[7 * k].c0[:])             # aimed at a sphere's centre: they hit something
+        rays[10 + k, 0:3] = centre - 3000.0 * np.array(dvec)
+        rays[10 + k, 3:6] = dvec
+        rays[10 + k, 6] = 0.0
     whole = H.hostsim_first_hit(d, rays)
+    assert np.isfinite(whole["t"][10:14]).all()
     lib = H.hostsim_lib()
     lib.sim_set_near_margin.argtypes = [ctypes.c_double]
     seen = []
@@ -150,7 +158,7 @@ def test_folded_table_walk_hands_rays_back_to_the_program_order():
         assert lib.sim_wide_walks() - wides == 1
         H.assert_aov_equal(whole, staged, f"folded table, margin {margin}")
         seen.append(lib.sim_order_redos())
-    assert 1 <= seen[0] <= 6 and seen[1] > 50 and seen[2] > seen[1], seen   # margin 0: the odd rays above, those that pass the root box
+    assert 1 <= seen[0] <= 10 and seen[1] > 50 and seen[2] > seen[1], seen   # margin 0: the odd rays above, those that pass the root box
 
 
 @pytest.mark.parametrize("n_prims", [30000, 30001, 50021])
