@@ -400,7 +400,8 @@ def test_sections_nearer_child_first_trace_the_same_paths(gpu_ctx, monkeypatch, 
 
 
 @pytest.mark.parametrize("recipe,near", [(recipes.large_bvh_beyond_lds, None), (recipes.empty_lists_and_media, None),
-                                         (recipes.nested_transforms, None), (recipes.ties_in_box_trees, None),
+                                         (recipes.nested_transforms, None), (recipes.nested_transforms, "per-ray"),
+                                         (recipes.ties_in_box_trees, None),
                                          (recipes.ties_in_box_trees, "2"), (recipes.ties_on_box_boundaries, None)],
                          ids=lambda v: getattr(v, "__name__", v))
 def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
@@ -408,10 +409,14 @@ def test_pipelines_agree_on_recipes(gpu_ctx, monkeypatch, recipe, near):
     memory walk, deferred box BVH), generic (box-bounded, transformed) media next to sphere-bounded ones, nested
     transforms, box trees full of coincident quads and spheres (walked nearer child first in the deferred section,
     and with RTX_WF_NEAR=2 in the head section as well).  The frame is 97 x 61 so that the 8 x 8 tiles are clipped on
-    both edges."""
-    if near is not None:
-        monkeypatch.setenv("RTX_WF_NEAR", near)
-    monkeypatch.setenv("RTX_WF_STREAM", "1")   # sections as streams (a call this small would walk them per ray by itself)
+    both edges.  "per-ray" leaves the sections to the kernel that walks the whole program for each ray: with transformed
+    leaves in the head section that is the general walk, not the sweep without transform contexts."""
+    if near == "per-ray":
+        monkeypatch.setenv("RTX_WF_STREAM", "0")
+    else:
+        if near is not None:
+            monkeypatch.setenv("RTX_WF_NEAR", near)
+        monkeypatch.setenv("RTX_WF_STREAM", "1")   # sections as streams (a call this small would walk them per ray by itself)
     gp = rt.Graph()
     wp, _, _ = recipe(gp)
     cam = rt.initialize_camera(rt.camera_desc(aspect_ratio=97.0 / 61.0, image_width=97, samples_per_pixel=9, max_depth=12,

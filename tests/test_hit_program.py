@@ -278,3 +278,16 @@ def test_flat_stretch_swept_in_step_is_the_same_walk(name):
         assert hits.value > len(rays) // 2
         if name == "final":
             assert media.value > 200
+
+
+def test_head_section_with_transformed_leaves_is_not_swept():
+    """The sweep's kernels walk the head section without transform contexts or media; a head section that holds any
+    (a BVH whose leaves are translated and rotated) must leave the program to the general walk."""
+    g = rt.Graph()
+    w, _, _ = recipes.nested_transforms(g)
+    desc = rt.flatten(g, w, None)
+    lib = H.hostsim_lib()
+    lib.sim_check_flat_walk.restype = ctypes.c_long
+    lib.sim_check_flat_walk.argtypes = [ctypes.POINTER(_capi.SceneDesc), H.PD, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    rays = np.zeros((1, 7))
+    assert lib.sim_check_flat_walk(ctypes.byref(desc), H.dptr(rays), 1, 0, None, None) == -1
